@@ -1,0 +1,197 @@
+/* libs4f_hip.so — C ABI of the MI355X (gfx950) S4Former training-step kernels.
+ *
+ * This is the drop-in boundary of the hot path.  The reference (a pure-Python mmseg fork)
+ * has no FFI of its own; every entry point below replaces the torch/ATen op(s) that the cited reference
+ * lines dispatch.  Conventions:
+ *   - all pointers are raw DEVICE pointers; the caller owns every buffer (outputs and workspaces included);
+ *   - the library never allocates, frees or synchronises; work is enqueued on `stream` and returns at once;
+ *   - return value 0 = ok, < 0 = error; the message is in s4f_last_error() (thread-local);
+ *   - `dtype` selects the operand type T of matrix operands / activations: S4F_F32 (parity mode: exact fp32
+ *     MFMA chain) or S4F_BF16 (perf mode: bf16 operands, fp32 accumulate).  Statistics, losses, master
+ *     weights, gradients of parameters and the residual stream are always fp32;
+ *   - re-entrant, no global mutable state, safe from several threads on different streams.
+ */
+#ifndef S4F_H_
+#define S4F_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* s4f_stream;      /* hipStream_t */
+#define S4F_F32 0
+#define S4F_BF16 1
+
+const char* s4f_last_error(void);
+int s4f_version(void);
+
+/* ------------------------------------------------------------------------------------------- GEMM family
+ * C[m,n] = alpha * sum_k A(m,k) * B(n,k)  (+ epilogue).  Replaces F.linear / nn.MultiheadAttention in/out
+ * projections / mmcv FFN (vit.py:86-103), the PatchEmbed conv (embed.py:145-153), ConvModule's Conv2d 3x3
+ * (setr_up_head.py:57-64) forward, input-gradient and weight-gradient, and conv_seg (decode_head.py:107).
+ *
+ * Operand addressing modes:
+ *   S4F_OP_ROW         X(i,k) = X[i*ld + k]                                  (contraction contiguous)
+ *   S4F_OP_K           X(i,k) = X[k*ld + i]                                  (contraction = rows)
+ *   S4F_OP_ROW_CONV    A only. i = pixel (b,y,x) of a [cB,cH,cW] grid, k = tap*cC + c, tap = 3*ty+tx:
+ *                      A(i,k) = X[pixel(b, y + sgn*(ty-1), x + sgn*(tx-1)) * ld + c], 0 outside the image.
+ *   S4F_OP_K_TAPSPLIT  B only (conv input-gradient weights, physical layout [co][ty][tx][ci]):
+ *                      k = tap*cC + co, n = ci:  B(n,k) = W[co*ld + tap*N + ci].
+ *   S4F_OP_K_CONV      B only (conv weight-gradient): k = pixel, n = tap*cC + c:
+ *                      B(n,k) = X[pixel shifted by +tap) * ld + c], 0 outside the image.
+ */
+#define S4F_OP_ROW 0
+#define S4F_OP_K 1
+#define S4F_OP_ROW_CONV 2
+#define S4F_OP_K_TAPSPLIT 3
+#define S4F_OP_K_CONV 4
+
+#define S4F_ACT_NONE 0
+#define S4F_ACT_GELU 1      /* out = gelu_erf(v); out_pre (if given) = v                      */
+#define S4F_ACT_GELU_BWD 2  /* out = v * gelu'(aux[m,n])                                       */
+
+typedef struct s4f_gemm_desc {
+  const void* A;
+  const void* B;
+  int32_t M, N, K;
+  int64_t lda, ldb;
+  int32_t a_mode, b_mode;
+  int32_t dtype;            /* type of A, B, out_t, out_pre, aux */
+  int32_t splitk;           /* >= 1; > 1 requires atomic = 1 */
+  /* conv geometry for the *_CONV / TAPSPLIT modes */
+  int32_t cB, cH, cW, cC, csign;
+  /* epilogue */
+  float alpha;
+  const float* bias;        /* [N] fp32 or NULL */
+  const float* resid;       /* fp32 [M, ldr] added to the result, or NULL */
+  int64_t ldr;
+  float* out_f32;           /* optional fp32 output [M, ldo_f32] */
+  int64_t ldo_f32;
+  void* out_t;              /* optional T output [M, ldo_t] */
+  int64_t ldo_t;
+  void* out_pre;            /* optional T output of the pre-activation value */
+  int64_t ldo_pre;
+  const void* aux;          /* T [M, ld_aux] (GELU_BWD) */
+  int64_t ld_aux;
+  int32_t act;
+  int32_t atomic;           /* 1: atomicAdd into out_f32 (which the caller pre-zeroed / accumulates into) */
+  /* token row map (patch embed): out row = m + m / rowmap_tpi + 1 ; adds pos[(m % tpi) + 1][n] */
+  int32_t rowmap_tpi;       /* 0 = identity */
+  const float* pos;         /* fp32 [(tpi+1), N] or NULL */
+} s4f_gemm_desc;
+
+int s4f_gemm(const s4f_gemm_desc* d, s4f_stream stream);
+
+/* ------------------------------------------------------------------------------------------- elementwise
+ * s4f_cast: fp32 -> T copy of n elements (parameter shadows).  */
+int s4f_cast(const float* src, void* dst, int64_t n, int dtype, s4f_stream stream);
+/* s4f_cast_back: T -> fp32 */
+int s4f_cast_back(const void* src, float* dst, int64_t n, int dtype, s4f_stream stream);
+
+/* PatchEmbed im2col (embed.py:183-204): img fp32 [B,3,H,W] -> cols T [B*(H/16)*(W/16), 768], feature order
+ * (c, ky, kx), token order row-major over the patch grid. H, W multiples of 16. */
+int s4f_im2col_patch16(const float* img, void* cols, int B, int H, int W, int dtype, s4f_stream stream);
+
+/* tokens[b, 0, :] = cls + pos[0]  (vit.py:486-487,445). tokens fp32 [B, ntok, C]. */
+int s4f_cls_pos(const float* cls, const float* pos, float* tokens, int B, int ntok, int C, s4f_stream stream);
+/* backward of token assembly: dpos[t,:] += sum_b dtok[b,t,:]; dcls += sum_b dtok[b,0,:] (atomic into fp32) */
+int s4f_tokens_bwd(const float* dtok, float* dpos, float* dcls, int B, int ntok, int C, s4f_stream stream);
+
+/* column sums (bias gradients): out[n] += sum_m X[m, n], X is T [M, ld]. */
+int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int dtype, s4f_stream stream);
+
+/* LayerNorm (vit.py:67-69,82-84; setr_up_head.py:49,103).  x fp32 rows; row r of the output reads input row
+ * r + r / rows_per_img * skip + skip (skip = 1 drops the cls token of each image: the head's token->NCHW
+ * reshape, vit.py:555-562, is folded into this index map; skip = 0 is the identity).
+ * y T [rows, C]; mean, rstd fp32 [rows]. C % 256 == 0, C <= 1024. */
+int s4f_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int rows, int C, int rows_per_img, int skip, float eps, int dtype, s4f_stream stream);
+/* dx[in_row] (=|+=) LN backward of dy (T) ; dgamma/dbeta accumulated atomically (fp32).
+ * dresid: optional fp32 gradient of the residual branch added to the result (same row map as x).
+ * dx fp32 output, dx_t optional T copy.  accumulate != 0: dx += (instead of =), dresid must then be NULL. */
+int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* dresid, float* dx, void* dx_t, float* dgamma, float* dbeta, int rows, int C,
+                      int rows_per_img, int skip, int accumulate, int dtype, s4f_stream stream);
+
+/* out = a + b (fp32), optional T copy of the sum */
+int s4f_add_f32(const float* a, const float* b, float* out, void* out_t, int64_t n, int dtype, s4f_stream stream);
+
+/* ------------------------------------------------------------------------------------------- attention
+ * nn.MultiheadAttention core (vit.py:99-103 via mmcv): qkv T [B, N, 3*H*64] (q | k | v, head h owns channels
+ * [64h, 64h+64) of each), S = (q k^T) / 8 + bias_w * bias_u[b, key] * (row_flag ? row_flag[b, query] : 1),
+ * P = softmax_keys(S), ctx = P v.  ctx T [B, N, H*64]; lse fp32 [B, H, N] (natural log-sum-exp of S).
+ * bias_u / row_flag: fp32 [B, N] or NULL (PASA rank-1 mask, vit.py:519-535). */
+int s4f_attention_fwd(const void* qkv, void* ctx, float* lse, const float* bias_u, const float* row_flag,
+                      float bias_w, int B, int N, int H, int dtype, s4f_stream stream);
+/* delta fp32 [B,H,N] workspace; dqkv T [B,N,3*H*64] fully overwritten. */
+int s4f_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta,
+                      void* dqkv, const float* bias_u, const float* row_flag, float bias_w, int B, int N, int H,
+                      int dtype, s4f_stream stream);
+
+/* ------------------------------------------------------------------------------------------- PUP head
+ * BatchNorm batch statistics of x T [rows, C] (NHWC rows = B*H*W): sums[0:C] += sum, sums[C:2C] += sum of squares */
+int s4f_bn_stats(const void* x, int64_t rows, int C, float* sums, int dtype, s4f_stream stream);
+/* From (all-reduced) sums -> per-channel scale/shift, mean, rstd; training: updates running stats
+ * (momentum 0.1, unbiased var) exactly as torch BatchNorm.  training = 0: uses running stats. */
+int s4f_bn_finalize(const float* sums, double count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
+                    float* mean, float* rstd, int C, s4f_stream stream);
+/* y = bilinear_up_s( relu(x * scale + shift) ), align_corners=False (ops/wrappers.py:46-51); x T [B,h,w,C],
+ * y T [B,h*s,w*s,C]; s >= 1 (s = 1: no resampling). */
+int s4f_bn_relu_up_fwd(const void* x, const float* scale, const float* shift, void* y, int B, int h, int w, int C,
+                       int s, int dtype, s4f_stream stream);
+/* g = up_s^T(dy) * (x*scale+shift > 0); g T [B,h,w,C]; sums[0:C] += sum g, sums[C:2C] += sum g * xhat,
+ * xhat = (x - mean) * rstd. */
+int s4f_bn_relu_up_bwd(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                       const float* rstd, void* g, float* sums, int B, int h, int w, int C, int s, int dtype,
+                       s4f_stream stream);
+/* dx = gamma * rstd * (g - sum_g/count - xhat * sum_gx/count); dgamma += sum_gx; dbeta += sum_g (local sums:
+ * pass the rank-local sums in sums_local for the parameter gradients, the all-reduced ones in sums). */
+int s4f_bn_bwd_apply(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma,
+                     const float* sums, double count, void* dx, int64_t rows, int C, int dtype, s4f_stream stream);
+int s4f_bn_param_grads(const float* sums_local, float* dgamma, float* dbeta, int C, s4f_stream stream);
+
+/* ------------------------------------------------------------------------------------------- losses
+ * logits_lo fp32 [B, h, w, ldc] (channels-last, first C columns valid).  The final bilinear upsample by s
+ * (align_corners=False) is applied on the fly: z = up_s(logits_lo) at [B, h*s, w*s].  (conv_seg and the
+ * upsample commute: both linear, interpolation weights sum to 1)
+ *
+ * CE with ignore_index, mean over ALL pixels (cross_entropy_loss.py:45-61, Q5):
+ *   loss_sum += sum_pixels [label != ignore] (logsumexp(z) - z[label])        (fp32 atomic, caller divides)
+ *   dlogits_hi T/fp32 is not materialised: dlo fp32 [B,h,w,ldc] += up_s^T( gscale * (softmax(z) - onehot) )
+ * labels: uint8 [B, h*s, w*s] (255 = ignore). Two launches: fwd (loss), bwd (dlo, recomputes softmax). */
+int s4f_upce_fwd(const float* logits_lo, const uint8_t* labels, float* loss_sum, int B, int h, int w, int C, int ldc,
+                 int s, int ignore_index, s4f_stream stream);
+int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, float gscale, float* dlo, void* dlo_t, int B, int h,
+                 int w, int C, int ldc, int s, int ignore_index, int dtype, s4f_stream stream);
+/* Teacher post-processing (encoder_decoder.py:888-901,541-542): label = argmax_c z (first index on ties),
+ * conf = 1/sum exp(z - zmax) > th; label_out = conf ? label : 255; conf_count += number of confident pixels.
+ * Also emits conf mask bytes (0/1) when conf_out != NULL. */
+int s4f_up_pseudo_label(const float* logits_lo, uint8_t* label_out, uint8_t* conf_out, unsigned long long* conf_count,
+                        float th, int B, int h, int w, int C, int ldc, int s, s4f_stream stream);
+/* full-resolution logits for the mmseg API: out fp32 NCHW [B, C, h*s, w*s] = up_s(logits_lo) */
+int s4f_up_logits_nchw(const float* logits_lo, float* out, int B, int h, int w, int C, int ldc, int s, s4f_stream stream);
+
+/* Stand-alone CrossEntropyLoss on NCHW / [N,C] fp32 logits (cross_entropy_loss.py:12-63): per-element loss
+ * (0 where ignored), optional class weights; spatial = H*W (1 for [N,C]). */
+int s4f_ce_fwd(const float* logits, const int64_t* labels, const float* class_weight, float* loss_elem, int64_t N,
+               int C, int64_t spatial, int64_t ignore_index, s4f_stream stream);
+int s4f_ce_bwd(const float* logits, const int64_t* labels, const float* class_weight, const float* dloss_elem,
+               float* dlogits, int64_t N, int C, int64_t spatial, int64_t ignore_index, s4f_stream stream);
+
+/* ------------------------------------------------------------------------------------------- optimiser / EMA
+ * update_ema_variables (encoder_decoder.py:1044-1066): t.mul_(m).add_(s, alpha=1-m) over a flat fp32 arena
+ * (= fma(s, 1-m, round(t*m)); both scalars are rounded to fp32 by the caller exactly as torch does);
+ * optional T shadow copy of the new teacher values. */
+int s4f_ema(float* teacher, const float* student, void* teacher_t, int64_t n, float momentum,
+            float one_minus_momentum, int dtype, s4f_stream stream);
+/* torch.optim.SGD(momentum, wd=0, dampening 0, nesterov False): first_step: buf = g else buf = mom*buf + g;
+ * p -= lr*buf; optional T shadow of p; grad_scale multiplies g first (DDP mean). Segments with different lr
+ * are separate calls on sub-ranges of the arenas. */
+int s4f_sgd_momentum(float* p, const float* g, float* buf, void* p_t, int64_t n, float lr, float momentum,
+                     float grad_scale, int first_step, int dtype, s4f_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,143 @@
+"""ORACLE (test infrastructure, never shipped, never on the product path).
+
+CPU restatement, in plain torch fp32, of the arithmetic of every op on the S4Former hot path.  Each function
+cites the reference file:line it follows (paths relative to the reference repo JoyHuYY1412/S4Former).  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+
+Parity status: pinned (a) by the reference's own known-answer CE tests (tests/golden/ce_known_answers.json,
+from reference tests/test_models/test_losses/test_ce_loss.py) and (b) by golden vectors generated in the build
+container from the reference's own hot-path files imported under a minimal mmcv stand-in
+(tests/golden/make_golden.py -> tests/golden/*.npz).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def linear(x, w, b=None):
+    """mmcv FFN / nn.MultiheadAttention projections (vit.py:86-103): y = x W^T + b."""
+    return F.linear(x, w, b)
+
+
+def gelu(x):
+    """nn.GELU() exact erf form (mmcv FFN act_cfg=dict(type='GELU'), vit.py:86-95)."""
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def layernorm(x, gamma, beta, eps=1e-6):
+    """nn.LayerNorm(768, eps=1e-6) (vit.py:67-69,82-84; setr_up_head.py:49,103): biased variance."""
+    return F.layer_norm(x, (x.shape[-1],), gamma, beta, eps)
+
+
+def patch_embed(img, w, b):
+    """PatchEmbed.forward (models/utils/embed.py:183-204): Conv2d k=s=16, flatten(2).transpose(1,2)."""
+    y = F.conv2d(img, w, b, stride=16)
+    hw = (y.shape[2], y.shape[3])
+    return y.flatten(2).transpose(1, 2), hw
+
+
+def assemble_tokens(patches, cls_token, pos_embed):
+    """vit.py:486-487,445: x = cat(cls, patches) + pos_embed (dropout p = 0)."""
+    B = patches.shape[0]
+    return torch.cat((cls_token.expand(B, -1, -1), patches), dim=1) + pos_embed
+
+
+def attention_core(qkv, num_heads, bias=None):
+    """nn.MultiheadAttention core as used by mmcv MultiheadAttention (vit.py:99-103):
+    q scaled by head_dim^-0.5 before the product, additive float mask [B, N, N] (same for all heads of an
+    image, vit.py:534-535), softmax over keys, P v, heads concatenated.  qkv [B, N, 3*h*dh] -> ctx [B, N, h*dh]."""
+    B, N, three_c = qkv.shape
+    c = three_c // 3
+    dh = c // num_heads
+    q, k, v = qkv.split(c, dim=-1)
+    q = q.reshape(B, N, num_heads, dh).transpose(1, 2) * (dh ** -0.5)
+    k = k.reshape(B, N, num_heads, dh).transpose(1, 2)
+    v = v.reshape(B, N, num_heads, dh).transpose(1, 2)
+    s = q @ k.transpose(-1, -2)
+    if bias is not None:
+        s = s + bias[:, None, :, :]
+    p = torch.softmax(s, dim=-1)
+    lse = torch.logsumexp(s, dim=-1)
+    ctx = (p @ v).transpose(1, 2).reshape(B, N, c)
+    return ctx, lse
+
+
+def pasa_bias(u, weight, adaptive):
+    """vit.py:519-535.  u [B, n_patches] = per-patch mean of (1 - conf).  Returns the additive mask [B, N, N]
+    (N = n_patches + 1, cls first with u = 0): bias[b, i, j] = weight * u_j, rows of the more-confident half
+    of the patch tokens zeroed when adaptive."""
+    B = u.shape[0]
+    um = torch.cat((torch.zeros(B, 1, dtype=u.dtype), u.reshape(B, -1)), dim=-1)
+    N = um.shape[-1]
+    m = um.unsqueeze(1).repeat(1, N, 1)
+    if adaptive:
+        idx = torch.topk(um[:, 1:], int(0.5 * (N - 1)), dim=-1, largest=False)[1] + 1
+        m[torch.arange(B).unsqueeze(1), idx, :] = 0
+    return m * weight
+
+
+def pasa_rank1(u, adaptive):
+    """The same mask in the rank-1 form the kernel takes: (bias_u [B,N], row_flag [B,N])."""
+    B = u.shape[0]
+    um = torch.cat((torch.zeros(B, 1, dtype=u.dtype), u.reshape(B, -1)), dim=-1)
+    N = um.shape[-1]
+    flag = torch.ones(B, N, dtype=u.dtype)
+    if adaptive:
+        idx = torch.topk(um[:, 1:], int(0.5 * (N - 1)), dim=-1, largest=False)[1] + 1
+        flag[torch.arange(B).unsqueeze(1), idx] = 0
+    return um, flag
+
+
+def conv3x3(x, w):
+    """ConvModule's Conv2d(k=3, pad=1, stride=1, bias=False) (setr_up_head.py:57-64). NCHW."""
+    return F.conv2d(x, w, None, stride=1, padding=1)
+
+
+def batchnorm_train(x, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5):
+    """(Sync)BatchNorm2d in train mode (configs/setr/*:11): batch statistics over (B,H,W), running stats updated
+    in place (unbiased variance)."""
+    return F.batch_norm(x, running_mean, running_var, gamma, beta, True, momentum, eps)
+
+
+def batchnorm_eval(x, gamma, beta, running_mean, running_var, eps=1e-5):
+    return F.batch_norm(x, running_mean, running_var, gamma, beta, False, 0.0, eps)
+
+
+def upsample(x, scale):
+    """mmseg.ops.Upsample (ops/wrappers.py:46-51): size = int(in * scale); F.interpolate(bilinear,
+    align_corners=False)."""
+    size = [int(t * scale) for t in x.shape[-2:]]
+    return F.interpolate(x, size, None, 'bilinear', False)
+
+
+def ce_mean_all(logits, label, ignore_index=255, loss_weight=1.0, class_weight=None):
+    """CrossEntropyLoss.forward with reduction='mean', avg_non_ignore=False (cross_entropy_loss.py:45-61,
+    losses/utils.py:68-69): per-pixel CE with ignored pixels contributing 0, mean over ALL pixels."""
+    loss = F.cross_entropy(logits, label, weight=class_weight, reduction='none', ignore_index=ignore_index)
+    return loss_weight * loss.mean()
+
+
+def ce_none(logits, label, ignore_index=-100, class_weight=None):
+    return F.cross_entropy(logits, label, weight=class_weight, reduction='none', ignore_index=ignore_index)
+
+
+def pseudo_label(seg_logits, th):
+    """extract_teacher_info_ema + foward_unsup_train (encoder_decoder.py:888-901,541-542)."""
+    max_value, label = torch.max(F.softmax(seg_logits, dim=1), dim=1)
+    conf = (max_value > th) * 1
+    label = label.clone()
+    label[conf == 0] = 255
+    return label, conf
+
+
+def ema_update(tgt, src, momentum):
+    """update_ema_variables (encoder_decoder.py:1058-1060): tgt.mul_(m).add_(src, alpha=1-m), in place."""
+    tgt.mul_(momentum).add_(src, alpha=1 - momentum)
+    return tgt
+
+
+def poly_lr(base_lr, it, max_iters, power=0.9, min_lr=1e-4):
+    """mmcv PolyLrUpdaterHook (schedule_80k_pascal_1over8.py:5): by_epoch=False."""
+    coeff = (1 - it / max_iters) ** power
+    return (base_lr - min_lr) * coeff + min_lr

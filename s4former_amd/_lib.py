@@ -1,0 +1,134 @@
+"""ctypes binding of libs4f_hip.so (the C ABI declared in include/s4f.h).
+
+The product path has no CPU fallback: if the library is missing this module raises at first use.
+Every wrapper takes torch tensors (device memory is owned by the caller = torch), passes raw pointers and the
+current HIP stream, and raises S4FError with the library's message on a non-zero return.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_void_p
+
+import torch
+
+F32, BF16 = 0, 1
+OP_ROW, OP_K, OP_ROW_CONV, OP_K_TAPSPLIT, OP_K_CONV = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libs4f_hip.so')
+_lib = None
+
+
+class S4FError(RuntimeError):
+    pass
+
+
+class GemmDesc(Structure):
+    _fields_ = [
+        ('A', c_void_p), ('B', c_void_p),
+        ('M', c_int32), ('N', c_int32), ('K', c_int32),
+        ('lda', c_int64), ('ldb', c_int64),
+        ('a_mode', c_int32), ('b_mode', c_int32),
+        ('dtype', c_int32), ('splitk', c_int32),
+        ('cB', c_int32), ('cH', c_int32), ('cW', c_int32), ('cC', c_int32), ('csign', c_int32),
+        ('alpha', c_float),
+        ('bias', c_void_p), ('resid', c_void_p), ('ldr', c_int64),
+        ('out_f32', c_void_p), ('ldo_f32', c_int64),
+        ('out_t', c_void_p), ('ldo_t', c_int64),
+        ('out_pre', c_void_p), ('ldo_pre', c_int64),
+        ('aux', c_void_p), ('ld_aux', c_int64),
+        ('act', c_int32), ('atomic', c_int32),
+        ('rowmap_tpi', c_int32), ('pos', c_void_p),
+    ]
+
+
+_SIGS = {
+    's4f_gemm': [POINTER(GemmDesc), c_void_p],
+    's4f_cast': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    's4f_cast_back': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    's4f_im2col_patch16': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_cls_pos': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    's4f_tokens_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    's4f_colsum': [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p],
+    's4f_layernorm_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                          c_float, c_int, c_void_p],
+    's4f_layernorm_bwd': [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_add_f32': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    's4f_attention_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
+                          c_void_p],
+    's4f_attention_bwd': [c_void_p] * 8 + [c_float, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_bn_stats': [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p],
+    's4f_bn_finalize': [c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
+                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    's4f_bn_relu_up_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_bn_relu_up_bwd': [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_bn_bwd_apply': [c_void_p] * 6 + [c_double, c_void_p, c_int64, c_int, c_int, c_void_p],
+    's4f_bn_param_grads': [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    's4f_upce_fwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_upce_bwd': [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                     c_int, c_int, c_void_p],
+    's4f_up_pseudo_label': [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int,
+                            c_int, c_void_p],
+    's4f_up_logits_nchw': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_ce_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p],
+    's4f_ce_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p],
+    's4f_ema': [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p],
+    's4f_sgd_momentum': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int, c_int,
+                         c_void_p],
+}
+EXPORTED_SYMBOLS = sorted(list(_SIGS) + ['s4f_last_error', 's4f_version'])
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def load():
+    """Load libs4f_hip.so (once). Raises S4FError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise S4FError(f'{_LIB_PATH} is missing: build it with `python -m s4former_amd.build` '
+                       '(there is no CPU fallback for the product path)')
+    lib = ctypes.CDLL(_LIB_PATH)
+    lib.s4f_last_error.restype = c_char_p
+    lib.s4f_last_error.argtypes = []
+    lib.s4f_version.restype = c_int
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = c_int
+        fn.argtypes = sig
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise S4FError(f'{name} failed ({rc}): {lib.s4f_last_error().decode(errors="replace")}')
+
+
+def dt(dtype):
+    if dtype in (BF16, torch.bfloat16):
+        return BF16
+    if dtype in (F32, torch.float32):
+        return F32
+    raise S4FError(f'unsupported compute dtype {dtype}')
+
+
+def torch_dtype(code):
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def p(t):
+    """device pointer of a tensor (None -> NULL)"""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise S4FError('s4f kernels need device tensors (got a CPU tensor); there is no CPU fallback')
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

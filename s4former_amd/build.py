@@ -1,0 +1,90 @@
+"""Build recipe of libs4f_hip.so (hipcc, gfx950 only).  `python -m s4former_amd.build` or `build_library()`.
+
+The shared library is built in-tree (s4former_amd/libs4f_hip.so) so that it travels to the GPU box with
+the repo snapshot; objects are cached under s4former_amd/csrc/_obj keyed by a hash of source + flags.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, 'csrc')
+OBJ_DIR = os.path.join(CSRC, '_obj')
+LIB_PATH = os.path.join(PKG_DIR, 'libs4f_hip.so')
+SOURCES = ['gemm.hip', 'attention.hip', 'elementwise.hip', 'head.hip']
+HEADERS = ['common.h', os.path.join('..', '..', 'include', 's4f.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off',
+         '-Wno-unused-result']
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError('hipcc not found')
+
+
+def _digest(paths, extra):
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, 'rb') as f:
+            h.update(f.read())
+    h.update(' '.join(extra).encode())
+    return h.hexdigest()[:16]
+
+
+def build_library(verbose=False, force=False):
+    """Compile every HIP source for gfx950 and link libs4f_hip.so. Returns the library path."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    jobs = []
+    objs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        tag = _digest([sp] + hdrs, FLAGS)
+        obj = os.path.join(OBJ_DIR, f'{os.path.splitext(src)[0]}.{tag}.o')
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            jobs.append((sp, obj))
+
+    def compile_one(job):
+        sp, obj = job
+        cmd = [hipcc] + FLAGS + ['-c', sp, '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {sp}:\n{r.stdout}\n{r.stderr}')
+        return obj
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
+            list(ex.map(compile_one, jobs))
+    link_tag = _digest(objs, ['link'])
+    stamp = os.path.join(OBJ_DIR, 'link.stamp')
+    old = open(stamp).read().strip() if os.path.exists(stamp) else ''
+    if force or jobs or old != link_tag or not os.path.exists(LIB_PATH):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+        with open(stamp, 'w') as f:
+            f.write(link_tag)
+    # drop stale objects
+    keep = set(os.path.basename(o) for o in objs) | {'link.stamp'}
+    for fn in os.listdir(OBJ_DIR):
+        if fn not in keep:
+            try:
+                os.remove(os.path.join(OBJ_DIR, fn))
+            except OSError:
+                pass
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    print(build_library(verbose=True, force='--force' in sys.argv))

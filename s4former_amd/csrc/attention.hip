@@ -1,0 +1,527 @@
+// Tiled (flash-style) multi-head attention for gfx950, head dim 64, no N x N tensor in HBM.
+// Replaces nn.MultiheadAttention's core inside mmcv's MultiheadAttention (reference vit.py:99-103,113-121):
+//   S = (q k^T)/8 + w * u[key] * flag[query];  P = softmax_keys(S);  ctx = P v
+// and its backward with recomputation from the saved log-sum-exp.
+//
+// Layout trick (guide §3 "an accumulator tile as the next MFMA's operand"): the forward and dQ kernels compute
+// S^T = K Q^T so that the query sits on the lane (softmax statistics are lane-local, one shuffle pair per
+// reduction) and two 16x16 accumulator tiles are, as they stand, the A operand (KMAP_TR order) of the P·V /
+// dS·K product, whose B operand (V / K, contraction = rows) comes from LDS by ds_read_b64_tr_b16.
+// The dK/dV kernel computes S = Q K^T (key on the lane) for the same reason.
+#include "common.h"
+#include "../../include/s4f.h"
+
+namespace {
+
+template <typename T> struct ACfg {
+  static constexpr int EPC = 16 / sizeof(T);
+  static constexpr int ROWB = 64 * sizeof(T);
+  static constexpr int STRIDE = ROWB + (sizeof(T) == 2 ? 32 : 16);   // 160 B / 272 B
+  static constexpr int CPR = ROWB / 16;
+  static constexpr int TILE_BYTES = 64 * STRIDE;
+};
+
+template <typename T> __device__ __forceinline__ float fexp(float x);
+template <> __device__ __forceinline__ float fexp<float>(float x) { return expf(x); }
+template <> __device__ __forceinline__ float fexp<bf16_t>(float x) { return __expf(x); }
+
+// cooperative load of a [64][64] T tile (rows row0.., zero beyond nrows) into a padded LDS image
+template <typename T, int NT>
+__device__ __forceinline__ void load_tile64(char* img, const T* src, long ld, int row0, int nrows) {
+  using C = ACfg<T>;
+  for (int c = threadIdx.x; c < 64 * C::CPR; c += NT) {
+    const int row = c / C::CPR, cc = c % C::CPR;
+    chunk16 v = zero16();
+    if (row0 + row < nrows) v = ld_global16(src + (long)(row0 + row) * ld + cc * C::EPC);
+    *reinterpret_cast<chunk16*>(img + row * C::STRIDE + cc * 16) = v;
+  }
+}
+
+// LINEAR-map fragment straight from global memory: 8 consecutive elements at p (or zeros)
+template <typename T> __device__ __forceinline__ void gload_frag(Frag<T>& f, const T* p, bool valid);
+template <> __device__ __forceinline__ void gload_frag<bf16_t>(Frag<bf16_t>& f, const bf16_t* p, bool valid) {
+  chunk16 c = valid ? ld_global16(p) : zero16();
+  f.v = *reinterpret_cast<bf16x8*>(&c);
+}
+template <> __device__ __forceinline__ void gload_frag<float>(Frag<float>& f, const float* p, bool valid) {
+  chunk16 a = valid ? ld_global16(p) : zero16();
+  chunk16 b = valid ? ld_global16(p + 4) : zero16();
+  const float* fa = reinterpret_cast<const float*>(&a);
+  const float* fb = reinterpret_cast<const float*>(&b);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = fa[j]; f.v[4 + j] = fb[j]; }
+}
+
+// row-read (LINEAR map) of a fragment from a padded [rows][64] image: row, d = 32 s + 8 g + j
+template <typename T>
+__device__ __forceinline__ void tile_rowfrag(Frag<T>& f, const char* img, int row, int s) {
+  const int g = (threadIdx.x & 63) >> 4;
+  lds_read_lin(f, img + row * ACfg<T>::STRIDE + (s * 32 + 8 * g) * (int)sizeof(T));
+}
+
+// two accumulator tiles (contraction rows 4g+r of sub-tiles 2ms, 2ms+1) -> A operand in KMAP_TR order
+template <typename T>
+__device__ __forceinline__ void acc_to_frag(Frag<T>& f, const f32x4& lo, const f32x4& hi) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { frag_set<T>(f, j, lo[j]); frag_set<T>(f, 4 + j, hi[j]); }
+}
+
+struct AttnArgs {
+  const void* qkv; void* ctx; float* lse;
+  const void* dctx; float* delta; void* dqkv;
+  const float* bias_u; const float* row_flag; float bias_w;
+  int B, N, H;
+};
+
+// ------------------------------------------------------------------------------------------ forward
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
+  using C = ACfg<T>;
+  constexpr int NT = 64 * NW;
+  __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES + 64 * 4];
+  char* Ks = smem;
+  char* Vs = smem + C::TILE_BYTES;
+  float* us = reinterpret_cast<float*>(smem + 2 * C::TILE_BYTES);
+
+  const int N = a.N, H = a.H;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
+  const long ld = 3L * H * 64;
+  const T* qb = reinterpret_cast<const T*>(a.qkv) + (long)b * N * ld + h * 64;
+  const T* kb = qb + H * 64;
+  const T* vb = qb + 2 * H * 64;
+  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  const bool has_bias = a.bias_u != nullptr;
+
+  Frag<T> fq[2][2];
+  float flagq[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + qt * 16 + li;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) gload_frag<T>(fq[qt][s], qb + (long)q * ld + s * 32 + 8 * g, q < N);
+    flagq[qt] = (has_bias && a.row_flag && q < N) ? a.row_flag[(long)b * N + q] : 1.f;
+  }
+  float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
+  f32x4 o[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < N; k0 += 64) {
+    __syncthreads();
+    load_tile64<T, NT>(Ks, kb, ld, k0, N);
+    load_tile64<T, NT>(Vs, vb, ld, k0, N);
+    if (threadIdx.x < 64) {
+      const int key = k0 + threadIdx.x;
+      us[threadIdx.x] = (has_bias && key < N) ? a.bias_w * a.bias_u[(long)b * N + key] : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 st[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) st[ks][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<T> fk;
+        tile_rowfrag<T>(fk, Ks, ks * 16 + li, s);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) st[ks][qt] = mma16(fk, fq[qt][s], st[ks][qt]);
+      }
+    // scale + bias + key mask, running max
+    float mloc[2] = {-INFINITY, -INFINITY};
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 uu = *reinterpret_cast<const f32x4*>(us + ks * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool kvalid = (k0 + ks * 16 + 4 * g + r) < N;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          float sv = st[ks][qt][r] * 0.125f + uu[r] * flagq[qt];
+          sv = kvalid ? sv : -INFINITY;
+          st[ks][qt][r] = sv;
+          mloc[qt] = fmaxf(mloc[qt], sv);
+        }
+      }
+    }
+    float alpha[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      float mx = mloc[qt];
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mnew = fmaxf(m[qt], mx);          // finite: every tile has >= 1 valid key
+      alpha[qt] = fexp<T>(m[qt] - mnew);            // m = -inf on the first tile -> 0
+      float ps = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fexp<T>(st[ks][qt][r] - mnew);
+          st[ks][qt][r] = p;
+          ps += p;
+        }
+      ps += __shfl_xor(ps, 16, 64);
+      ps += __shfl_xor(ps, 32, 64);
+      lsum[qt] = lsum[qt] * alpha[qt] + ps;
+      m[qt] = mnew;
+    }
+    // rescale O (rows of O are queries 4g + r -> fetch alpha from the lane that owns that query)
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float al = __shfl(alpha[qt], 4 * g + r, 64);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[qt][dt][r] *= al;
+      }
+    // O += P V
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      Frag<T> pa[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) acc_to_frag<T>(pa[qt], st[2 * ms][qt], st[2 * ms + 1][qt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        Frag<T> fv;
+        lds_read_tr(fv, Vs, C::STRIDE, ms * 32, dt * 16);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mma16(pa[qt], fv, o[qt][dt]);
+      }
+    }
+  }
+
+  T* cb = reinterpret_cast<T*>(a.ctx) + (long)b * N * (H * 64) + h * 64;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float il = 1.f / lsum[qt];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ilr = __shfl(il, 4 * g + r, 64);
+      const int q = q0 + qt * 16 + 4 * g + r;
+      if (q < N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) cb[(long)q * (H * 64) + dt * 16 + li] = from_f32<T>(o[qt][dt][r] * ilr);
+      }
+    }
+    const int q = q0 + qt * 16 + li;
+    if (g == 0 && q < N) a.lse[((long)b * H + h) * N + q] = m[qt] + logf(lsum[qt]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+template <typename T>
+__global__ void attn_delta_kernel(const T* ctx, const T* dctx, float* delta, int B, int N, int H) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, q, h)
+  const long total = (long)B * N * H;
+  if (idx >= total) return;
+  const int h = idx % H;
+  const long bq = idx / H;
+  const int q = bq % N;
+  const int b = bq / N;
+  const T* o = ctx + bq * (H * 64) + h * 64;
+  const T* d = dctx + bq * (H * 64) + h * 64;
+  float s = 0.f;
+#pragma unroll 8
+  for (int i = 0; i < 64; ++i) s += to_f32<T>(o[i]) * to_f32<T>(d[i]);
+  delta[((long)b * H + h) * N + q] = s;
+}
+
+// ------------------------------------------------------------------------------------------ dQ
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
+  using C = ACfg<T>;
+  constexpr int NT = 64 * NW;
+  __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES + 64 * 4];
+  char* Ks = smem;
+  char* Vs = smem + C::TILE_BYTES;
+  float* us = reinterpret_cast<float*>(smem + 2 * C::TILE_BYTES);
+
+  const int N = a.N, H = a.H;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
+  const long ld = 3L * H * 64, ldc = H * 64;
+  const T* qb = reinterpret_cast<const T*>(a.qkv) + (long)b * N * ld + h * 64;
+  const T* kb = qb + H * 64;
+  const T* vb = qb + 2 * H * 64;
+  const T* dob = reinterpret_cast<const T*>(a.dctx) + (long)b * N * ldc + h * 64;
+  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  const bool has_bias = a.bias_u != nullptr;
+
+  Frag<T> fq[2][2], fdo[2][2];
+  float flagq[2], lseq[2], delq[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + qt * 16 + li;
+    const bool v = q < N;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      gload_frag<T>(fq[qt][s], qb + (long)q * ld + s * 32 + 8 * g, v);
+      gload_frag<T>(fdo[qt][s], dob + (long)q * ldc + s * 32 + 8 * g, v);
+    }
+    flagq[qt] = (has_bias && a.row_flag && v) ? a.row_flag[(long)b * N + q] : 1.f;
+    lseq[qt] = v ? a.lse[((long)b * H + h) * N + q] : 0.f;
+    delq[qt] = v ? a.delta[((long)b * H + h) * N + q] : 0.f;
+  }
+  f32x4 dq[2][4];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int k0 = 0; k0 < N; k0 += 64) {
+    __syncthreads();
+    load_tile64<T, NT>(Ks, kb, ld, k0, N);
+    load_tile64<T, NT>(Vs, vb, ld, k0, N);
+    if (threadIdx.x < 64) {
+      const int key = k0 + threadIdx.x;
+      us[threadIdx.x] = (has_bias && key < N) ? a.bias_w * a.bias_u[(long)b * N + key] : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 st[4][2], dp[4][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) { st[ks][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[ks][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        Frag<T> fk, fv;
+        tile_rowfrag<T>(fk, Ks, ks * 16 + li, s);
+        tile_rowfrag<T>(fv, Vs, ks * 16 + li, s);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          st[ks][qt] = mma16(fk, fq[qt][s], st[ks][qt]);
+          dp[ks][qt] = mma16(fv, fdo[qt][s], dp[ks][qt]);
+        }
+      }
+    // dS^T = P * (dP^T - delta)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 uu = *reinterpret_cast<const f32x4*>(us + ks * 16 + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool kvalid = (k0 + ks * 16 + 4 * g + r) < N;
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const float sv = st[ks][qt][r] * 0.125f + uu[r] * flagq[qt];
+          const float p = kvalid ? fexp<T>(sv - lseq[qt]) : 0.f;
+          st[ks][qt][r] = p * (dp[ks][qt][r] - delq[qt]);
+        }
+      }
+    }
+    // dQ += dS K
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      Frag<T> pa[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) acc_to_frag<T>(pa[qt], st[2 * ms][qt], st[2 * ms + 1][qt]);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        Frag<T> fk;
+        lds_read_tr(fk, Ks, C::STRIDE, ms * 32, dt * 16);
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) dq[qt][dt] = mma16(pa[qt], fk, dq[qt][dt]);
+      }
+    }
+  }
+  T* dqb = reinterpret_cast<T*>(a.dqkv) + (long)b * N * ld + h * 64;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = q0 + qt * 16 + 4 * g + r;
+      if (q < N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) dqb[(long)q * ld + dt * 16 + li] = from_f32<T>(dq[qt][dt][r] * 0.125f);
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ dK, dV
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
+  using C = ACfg<T>;
+  constexpr int NT = 64 * NW;
+  __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES + 3 * 64 * 4];
+  char* Qs = smem;
+  char* Ds = smem + C::TILE_BYTES;
+  float* lses = reinterpret_cast<float*>(smem + 2 * C::TILE_BYTES);
+  float* dels = lses + 64;
+  float* flgs = dels + 64;
+
+  const int N = a.N, H = a.H;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
+  const long ld = 3L * H * 64, ldc = H * 64;
+  const T* qb = reinterpret_cast<const T*>(a.qkv) + (long)b * N * ld + h * 64;
+  const T* kb = qb + H * 64;
+  const T* vb = qb + 2 * H * 64;
+  const T* dob = reinterpret_cast<const T*>(a.dctx) + (long)b * N * ldc + h * 64;
+  const int key0 = blockIdx.x * 32 * NW + wave * 32;
+  const bool has_bias = a.bias_u != nullptr;
+
+  Frag<T> fk[2][2], fv[2][2];
+  float uk[2];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int key = key0 + kt * 16 + li;
+    const bool v = key < N;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      gload_frag<T>(fk[kt][s], kb + (long)key * ld + s * 32 + 8 * g, v);
+      gload_frag<T>(fv[kt][s], vb + (long)key * ld + s * 32 + 8 * g, v);
+    }
+    uk[kt] = (has_bias && v) ? a.bias_w * a.bias_u[(long)b * N + key] : 0.f;
+  }
+  f32x4 dk[2][4], dv[2][4];
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  for (int q0 = 0; q0 < N; q0 += 64) {
+    __syncthreads();
+    load_tile64<T, NT>(Qs, qb, ld, q0, N);
+    load_tile64<T, NT>(Ds, dob, ldc, q0, N);
+    if (threadIdx.x < 64) {
+      const int q = q0 + threadIdx.x;
+      const bool v = q < N;
+      lses[threadIdx.x] = v ? a.lse[((long)b * H + h) * N + q] : 0.f;
+      dels[threadIdx.x] = v ? a.delta[((long)b * H + h) * N + q] : 0.f;
+      flgs[threadIdx.x] = (has_bias && a.row_flag && v) ? a.row_flag[(long)b * N + q] : 1.f;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+      // S[q][key], dP[q][key] for the 32 queries of this macro step (2 sub-tiles), 32 keys of this wave
+      f32x4 sc[2][2], dp[2][2];
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { sc[qs][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qs][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int qs = 0; qs < 2; ++qs) {
+          Frag<T> fqr, fdr;
+          tile_rowfrag<T>(fqr, Qs, ms * 32 + qs * 16 + li, s);
+          tile_rowfrag<T>(fdr, Ds, ms * 32 + qs * 16 + li, s);
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            sc[qs][kt] = mma16(fqr, fk[kt][s], sc[qs][kt]);
+            dp[qs][kt] = mma16(fdr, fv[kt][s], dp[qs][kt]);
+          }
+        }
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        const int qo = ms * 32 + qs * 16 + 4 * g;
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(lses + qo);
+        const f32x4 de = *reinterpret_cast<const f32x4*>(dels + qo);
+        const f32x4 fl = *reinterpret_cast<const f32x4*>(flgs + qo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool qvalid = (q0 + qo + r) < N;
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            const float sv = sc[qs][kt][r] * 0.125f + uk[kt] * fl[r];
+            const float p = qvalid ? fexp<T>(sv - ls[r]) : 0.f;
+            sc[qs][kt][r] = p;
+            dp[qs][kt][r] = p * (dp[qs][kt][r] - de[r]);
+          }
+        }
+      }
+      // dV[key][d] += sum_q P[q][key] dO[q][d] ;  dK[key][d] += sum_q dS[q][key] Q[q][d]
+      Frag<T> pa[2], da[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        acc_to_frag<T>(pa[kt], sc[0][kt], sc[1][kt]);
+        acc_to_frag<T>(da[kt], dp[0][kt], dp[1][kt]);
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        Frag<T> fdo, fqq;
+        lds_read_tr(fdo, Ds, C::STRIDE, ms * 32, dt * 16);
+        lds_read_tr(fqq, Qs, C::STRIDE, ms * 32, dt * 16);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+          dv[kt][dt] = mma16(pa[kt], fdo, dv[kt][dt]);
+          dk[kt][dt] = mma16(da[kt], fqq, dk[kt][dt]);
+        }
+      }
+    }
+  }
+  T* dkb = reinterpret_cast<T*>(a.dqkv) + (long)b * N * ld + H * 64 + h * 64;
+  T* dvb = dkb + H * 64;
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = key0 + kt * 16 + 4 * g + r;
+      if (key < N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dkb[(long)key * ld + dt * 16 + li] = from_f32<T>(dk[kt][dt][r] * 0.125f);
+          dvb[(long)key * ld + dt * 16 + li] = from_f32<T>(dv[kt][dt][r]);
+        }
+      }
+    }
+}
+
+constexpr int kNW = 2;
+
+template <typename T>
+int fwd_launch(const AttnArgs& a, hipStream_t st) {
+  dim3 grid(ceil_div(a.N, 32 * kNW), a.H, a.B);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, kNW>), grid, dim3(64 * kNW), 0, st, a);
+  return 0;
+}
+template <typename T>
+int bwd_launch(const AttnArgs& a, hipStream_t st) {
+  const long total = (long)a.B * a.N * a.H;
+  hipLaunchKernelGGL((attn_delta_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const T*>(a.ctx), reinterpret_cast<const T*>(a.dctx), a.delta, a.B, a.N, a.H);
+  dim3 grid(ceil_div(a.N, 32 * kNW), a.H, a.B);
+  hipLaunchKernelGGL((attn_dq_kernel<T, kNW>), grid, dim3(64 * kNW), 0, st, a);
+  hipLaunchKernelGGL((attn_dkv_kernel<T, kNW>), grid, dim3(64 * kNW), 0, st, a);
+  return 0;
+}
+
+}  // namespace
+
+S4F_API int s4f_attention_fwd(const void* qkv, void* ctx, float* lse, const float* bias_u, const float* row_flag,
+                              float bias_w, int B, int N, int H, int dtype, s4f_stream stream) {
+  S4F_CHECK(qkv && ctx && lse, "s4f_attention_fwd: null pointer");
+  S4F_CHECK(B > 0 && N > 0 && H > 0, "s4f_attention_fwd: bad dims");
+  S4F_CHECK(dtype == S4F_F32 || dtype == S4F_BF16, "s4f_attention_fwd: bad dtype");
+  S4F_CHECK(((uintptr_t)qkv % 16) == 0 && ((uintptr_t)ctx % 16) == 0, "s4f_attention_fwd: 16-B alignment");
+  AttnArgs a{};
+  a.qkv = qkv; a.ctx = ctx; a.lse = lse; a.bias_u = bias_u; a.row_flag = row_flag; a.bias_w = bias_w;
+  a.B = B; a.N = N; a.H = H;
+  if (dtype == S4F_BF16) fwd_launch<bf16_t>(a, (hipStream_t)stream); else fwd_launch<float>(a, (hipStream_t)stream);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta,
+                              void* dqkv, const float* bias_u, const float* row_flag, float bias_w, int B, int N,
+                              int H, int dtype, s4f_stream stream) {
+  S4F_CHECK(qkv && ctx && dctx && lse && delta && dqkv, "s4f_attention_bwd: null pointer");
+  S4F_CHECK(B > 0 && N > 0 && H > 0, "s4f_attention_bwd: bad dims");
+  S4F_CHECK(dtype == S4F_F32 || dtype == S4F_BF16, "s4f_attention_bwd: bad dtype");
+  AttnArgs a{};
+  a.qkv = qkv; a.ctx = const_cast<void*>(ctx); a.dctx = dctx; a.lse = const_cast<float*>(lse); a.delta = delta;
+  a.dqkv = dqkv; a.bias_u = bias_u; a.row_flag = row_flag; a.bias_w = bias_w; a.B = B; a.N = N; a.H = H;
+  if (dtype == S4F_BF16) bwd_launch<bf16_t>(a, (hipStream_t)stream); else bwd_launch<float>(a, (hipStream_t)stream);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}

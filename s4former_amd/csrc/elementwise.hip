@@ -1,0 +1,454 @@
+// Memory-bound kernels of the ViT trunk and the optimiser: casts, patch im2col, token assembly, bias-gradient
+// column sums, LayerNorm fwd/bwd, multi-tensor EMA and SGD over flat fp32 arenas.  All are HBM-bound: 16-byte
+// accesses per lane, grid-stride loops capped at ~2048 blocks (guide G11/G13).
+#include "common.h"
+#include "../../include/s4f.h"
+
+thread_local char s4f_err_buf[512] = {0};
+
+S4F_API const char* s4f_last_error(void) { return s4f_err_buf; }
+S4F_API int s4f_version(void) { return 100; }
+
+namespace {
+
+constexpr int kMaxBlocks = 2048;
+inline int grid_for(long work_items, int per_block) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------- casts
+template <typename T>
+__global__ void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, long n) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(src)[i];
+    if constexpr (sizeof(T) == 2) {
+      bf16x4 o;
+      o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+      reinterpret_cast<bf16x4*>(dst)[i] = o;
+    } else {
+      reinterpret_cast<f32x4*>(dst)[i] = v;
+    }
+  }
+  const long tail0 = n4 << 2;
+  for (long i = tail0 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = from_f32<T>(src[i]);
+}
+template <typename T>
+__global__ void cast_back_kernel(const T* __restrict__ src, float* __restrict__ dst, long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = to_f32<T>(src[i]);
+}
+
+// ---------------------------------------------------------------- patch im2col (16x16, stride 16)
+// one thread per 4 consecutive kx of one (token, c, ky): reads 16 B of the image row, writes 4 features.
+template <typename T>
+__global__ void im2col16_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H, int W) {
+  const int gh = H / 16, gw = W / 16;
+  const long total = (long)B * gh * gw * 192;   // 768 / 4 groups per token
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int f4 = i % 192;            // feature group: features 4*f4 .. 4*f4+3 = (c, ky, kx0..kx0+3)
+    const long tok = i / 192;
+    const int c = f4 / 64;
+    const int ky = (f4 % 64) / 4;
+    const int kx0 = (f4 % 4) * 4;
+    const int px = tok % gw;
+    const long t2 = tok / gw;
+    const int py = t2 % gh;
+    const int b = t2 / gh;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(img + (((long)b * 3 + c) * H + (py * 16 + ky)) * W + px * 16 + kx0);
+    T* o = cols + tok * 768 + f4 * 4;
+    if constexpr (sizeof(T) == 2) {
+      bf16x4 ov;
+      ov[0] = (bf16_t)v[0]; ov[1] = (bf16_t)v[1]; ov[2] = (bf16_t)v[2]; ov[3] = (bf16_t)v[3];
+      *reinterpret_cast<bf16x4*>(o) = ov;
+    } else {
+      *reinterpret_cast<f32x4*>(o) = v;
+    }
+  }
+}
+
+__global__ void cls_pos_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ tok,
+                               int B, int ntok, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int b = i / C, c = i % C;
+  tok[(long)b * ntok * C + c] = cls[c] + pos[c];
+}
+
+// dpos[t, c] += sum_b dtok[b, t, c]; dcls[c] += sum_b dtok[b, 0, c]
+__global__ void tokens_bwd_kernel(const float* __restrict__ dtok, float* __restrict__ dpos, float* __restrict__ dcls,
+                                  int B, int ntok, int C) {
+  const long total = (long)ntok * C;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dtok[(long)b * total + i];
+    atomicAdd(dpos + i, s);
+    if (i < C) atomicAdd(dcls + i, s);
+  }
+}
+
+// ---------------------------------------------------------------- column sums
+// block = 256 threads = 64 columns x 4 row lanes; grid.x = column blocks of 64, grid.y = row slabs
+template <typename T>
+__global__ void colsum_kernel(const T* __restrict__ X, long ld, int M, int N, float* __restrict__ out, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + cx;
+  const int r0 = blockIdx.y * rows_per_block;
+  int r1 = r0 + rows_per_block;
+  if (r1 > M) r1 = M;
+  float s = 0.f;
+  if (col < N)
+    for (int r = r0 + ry; r < r1; r += 4) s += to_f32<T>(X[(long)r * ld + col]);
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && col < N) atomicAdd(out + col, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+}
+
+// ---------------------------------------------------------------- LayerNorm
+// one wave per row; lane holds NV groups of 4 consecutive channels: channel = v*256 + lane*4 + e
+__device__ __forceinline__ long ln_in_row(int r, int rows_per_img, int skip) {
+  return skip ? (long)r + (long)(r / rows_per_img) * skip + skip : (long)r;
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, T* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                     int rows_per_img, int skip, float eps) {
+  constexpr int C = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  f32x4 gm[NV], bt[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    gm[v] = *reinterpret_cast<const f32x4*>(gamma + v * 256 + lane * 4);
+    bt[v] = *reinterpret_cast<const f32x4*>(beta + v * 256 + lane * 4);
+  }
+  for (int r = wave_global; r < rows; r += nwaves) {
+    const float* xr = x + ln_in_row(r, rows_per_img, skip) * C;
+    f32x4 xv[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      xv[v] = *reinterpret_cast<const f32x4*>(xr + v * 256 + lane * 4);
+      s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
+    }
+    const float mu = wave_sum(s) * (1.f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = xv[v][e] - mu; q += d * d; }
+    const float var = wave_sum(q) * (1.f / C);
+    const float rs = 1.f / sqrtf(var + eps);
+    T* yr = y + (long)r * C;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (xv[v][e] - mu) * rs * gm[v][e] + bt[v][e];
+      if constexpr (sizeof(T) == 2) {
+        bf16x4 ob;
+        ob[0] = (bf16_t)o[0]; ob[1] = (bf16_t)o[1]; ob[2] = (bf16_t)o[2]; ob[3] = (bf16_t)o[3];
+        *reinterpret_cast<bf16x4*>(yr + v * 256 + lane * 4) = ob;
+      } else {
+        *reinterpret_cast<f32x4*>(yr + v * 256 + lane * 4) = o;
+      }
+    }
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+  }
+}
+
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+  const bf16x4 b = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+  bf16x4 b;
+  b[0] = (bf16_t)v[0]; b[1] = (bf16_t)v[1]; b[2] = (bf16_t)v[2]; b[3] = (bf16_t)v[3];
+  *reinterpret_cast<bf16x4*>(p) = b;
+}
+
+// dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * gamma ; dgamma += dy * xhat ; dbeta += dy
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ dresid,
+                                                     float* __restrict__ dx, T* __restrict__ dx_t,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
+                                                     int rows_per_img, int skip, int accumulate) {
+  constexpr int C = NV * 256;
+  __shared__ float red[2][4][C];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * blockDim.x) >> 6;
+  f32x4 gm[NV], dg[NV], db[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    gm[v] = *reinterpret_cast<const f32x4*>(gamma + v * 256 + lane * 4);
+    dg[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    db[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int r = wave_global; r < rows; r += nwaves) {
+    const long ir = ln_in_row(r, rows_per_img, skip);
+    const float* xr = x + ir * C;
+    const T* dyr = dy + (long)r * C;
+    const float mu = mean[r], rs = rstd[r];
+    f32x4 xh[NV], dyv[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + v * 256 + lane * 4);
+      dyv[v] = load4<T>(dyr + v * 256 + lane * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[v][e] = (xv[e] - mu) * rs;
+        const float dyg = dyv[v][e] * gm[v][e];
+        s1 += dyg;
+        s2 += dyg * xh[v][e];
+        dg[v][e] += dyv[v][e] * xh[v][e];
+        db[v][e] += dyv[v][e];
+      }
+    }
+    s1 = wave_sum(s1) * (1.f / C);
+    s2 = wave_sum(s2) * (1.f / C);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rs * (dyv[v][e] * gm[v][e] - s1 - xh[v][e] * s2);
+      float* dxr = dx + ir * C + v * 256 + lane * 4;
+      if (dresid) {
+        const f32x4 dr = *reinterpret_cast<const f32x4*>(dresid + ir * C + v * 256 + lane * 4);
+        o += dr;
+      } else if (accumulate) {
+        o += *reinterpret_cast<const f32x4*>(dxr);
+      }
+      *reinterpret_cast<f32x4*>(dxr) = o;
+      if (dx_t) store4<T>(dx_t + ir * C + v * 256 + lane * 4, o);
+    }
+  }
+  // block reduction of dgamma / dbeta, then one atomic per column per block
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][wave][v * 256 + lane * 4 + e] = dg[v][e];
+      red[1][wave][v * 256 + lane * 4 + e] = db[v][e];
+    }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+template <typename T>
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                           T* __restrict__ out_t, long n) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(a)[i] + reinterpret_cast<const f32x4*>(b)[i];
+    reinterpret_cast<f32x4*>(out)[i] = v;
+    if (out_t) store4<T>(out_t + 4 * i, v);
+  }
+}
+
+// ---------------------------------------------------------------- EMA / SGD over flat arenas
+template <typename T>
+__global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, T* __restrict__ tt, long n, float m,
+                           float om) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 tv = reinterpret_cast<f32x4*>(t)[i];
+    const f32x4 sv = reinterpret_cast<const f32x4*>(s)[i];
+    // torch: t.mul_(m).add_(s, alpha=1-m) = fma(s, 1-m, round(t*m)) (ATen's add kernel uses fmadd)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tv[e] = __fmaf_rn(sv[e], om, __fmul_rn(tv[e], m));
+    reinterpret_cast<f32x4*>(t)[i] = tv;
+    if (tt) store4<T>(tt + 4 * i, tv);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = __fmaf_rn(s[i], om, __fmul_rn(t[i], m));
+    t[i] = v;
+    if (tt) tt[i] = from_f32<T>(v);
+  }
+}
+
+template <typename T>
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                           T* __restrict__ pt, long n, float lr, float mom, float gs, int first) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gv = reinterpret_cast<const f32x4*>(g)[i];
+    f32x4 bv = first ? f32x4{0.f, 0.f, 0.f, 0.f} : reinterpret_cast<f32x4*>(buf)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ge = gs == 1.f ? gv[e] : __fmul_rn(gv[e], gs);
+      bv[e] = first ? ge : __fadd_rn(__fmul_rn(bv[e], mom), ge);
+      pv[e] = __fmaf_rn(bv[e], -lr, pv[e]);   // p.add_(buf, alpha=-lr)
+    }
+    reinterpret_cast<f32x4*>(buf)[i] = bv;
+    reinterpret_cast<f32x4*>(p)[i] = pv;
+    if (pt) store4<T>(pt + 4 * i, pv);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float ge = gs == 1.f ? g[i] : __fmul_rn(g[i], gs);
+    const float b = first ? ge : __fadd_rn(__fmul_rn(buf[i], mom), ge);
+    const float v = __fmaf_rn(b, -lr, p[i]);
+    buf[i] = b; p[i] = v;
+    if (pt) pt[i] = from_f32<T>(v);
+  }
+}
+
+}  // namespace
+
+#define DT_CHECK(name) S4F_CHECK(dtype == S4F_F32 || dtype == S4F_BF16, name ": bad dtype %d", dtype)
+
+S4F_API int s4f_cast(const float* src, void* dst, int64_t n, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_cast");
+  S4F_CHECK(src && dst && n >= 0, "s4f_cast: bad args");
+  if (n == 0) return 0;
+  S4F_CHECK(((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 8) == 0, "s4f_cast: alignment");
+  const int grid = grid_for(n / 4 + 1, 256);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(cast_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, (long)n);
+  else hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, (long)n);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_cast_back(const void* src, float* dst, int64_t n, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_cast_back");
+  S4F_CHECK(src && dst && n >= 0, "s4f_cast_back: bad args");
+  if (n == 0) return 0;
+  const int grid = grid_for(n, 256);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(cast_back_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, (long)n);
+  else hipLaunchKernelGGL(cast_back_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, (long)n);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_im2col_patch16(const float* img, void* cols, int B, int H, int W, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_im2col_patch16");
+  S4F_CHECK(img && cols && B > 0, "s4f_im2col_patch16: bad args");
+  S4F_CHECK(H % 16 == 0 && W % 16 == 0 && H > 0 && W > 0, "s4f_im2col_patch16: H, W must be multiples of 16 (got %d x %d)", H, W);
+  S4F_CHECK(((uintptr_t)img % 16) == 0, "s4f_im2col_patch16: img must be 16-B aligned");
+  const long total = (long)B * (H / 16) * (W / 16) * 192;
+  const int grid = grid_for(total, 256);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(im2col16_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, B, H, W);
+  else hipLaunchKernelGGL(im2col16_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, H, W);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_cls_pos(const float* cls, const float* pos, float* tokens, int B, int ntok, int C, s4f_stream stream) {
+  S4F_CHECK(cls && pos && tokens && B > 0 && ntok > 0 && C > 0, "s4f_cls_pos: bad args");
+  hipLaunchKernelGGL(cls_pos_kernel, dim3(ceil_div((long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, cls, pos, tokens, B, ntok, C);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_tokens_bwd(const float* dtok, float* dpos, float* dcls, int B, int ntok, int C, s4f_stream stream) {
+  S4F_CHECK(dtok && dpos && dcls && B > 0 && ntok > 0 && C > 0, "s4f_tokens_bwd: bad args");
+  hipLaunchKernelGGL(tokens_bwd_kernel, dim3(grid_for((long)ntok * C, 256)), dim3(256), 0, (hipStream_t)stream, dtok, dpos, dcls, B, ntok, C);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_colsum");
+  S4F_CHECK(X && out && M > 0 && N > 0 && ld >= N, "s4f_colsum: bad args");
+  const int rows_per_block = 128;
+  dim3 grid(ceil_div(N, 64), ceil_div(M, rows_per_block));
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, (long)ld, M, N, out, rows_per_block);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, (long)ld, M, N, out, rows_per_block);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+#define LN_DISPATCH(KERNEL, TT, ...)                                                                              \
+  switch (C / 256) {                                                                                              \
+    case 1: hipLaunchKernelGGL((KERNEL<TT, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 2: hipLaunchKernelGGL((KERNEL<TT, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 3: hipLaunchKernelGGL((KERNEL<TT, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((KERNEL<TT, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+  }
+
+S4F_API int s4f_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                              int rows, int C, int rows_per_img, int skip, float eps, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_layernorm_fwd");
+  S4F_CHECK(x && gamma && beta && y && mean && rstd, "s4f_layernorm_fwd: null pointer");
+  S4F_CHECK(rows > 0 && C % 256 == 0 && C >= 256 && C <= 1024, "s4f_layernorm_fwd: C=%d must be a multiple of 256, <= 1024", C);
+  S4F_CHECK(skip == 0 || rows_per_img > 0, "s4f_layernorm_fwd: rows_per_img needed with skip");
+  const int grid = grid_for(rows, 4);
+  if (dtype == S4F_BF16) { LN_DISPATCH(ln_fwd_kernel, bf16_t, x, gamma, beta, (bf16_t*)y, mean, rstd, rows, rows_per_img, skip, eps) }
+  else { LN_DISPATCH(ln_fwd_kernel, float, x, gamma, beta, (float*)y, mean, rstd, rows, rows_per_img, skip, eps) }
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                              const float* dresid, float* dx, void* dx_t, float* dgamma, float* dbeta, int rows, int C,
+                              int rows_per_img, int skip, int accumulate, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_layernorm_bwd");
+  S4F_CHECK(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "s4f_layernorm_bwd: null pointer");
+  S4F_CHECK(rows > 0 && C % 256 == 0 && C >= 256 && C <= 1024, "s4f_layernorm_bwd: C=%d must be a multiple of 256, <= 1024", C);
+  S4F_CHECK(!(accumulate && dresid), "s4f_layernorm_bwd: accumulate and dresid are exclusive");
+  S4F_CHECK(skip == 0 || rows_per_img > 0, "s4f_layernorm_bwd: rows_per_img needed with skip");
+  int grid = grid_for(rows, 16);   // 4 rows per wave: fewer atomics on dgamma/dbeta
+  if (grid > 512) grid = 512;
+  if (dtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)dy, x, mean, rstd, gamma, dresid, dx, (bf16_t*)dx_t, dgamma, dbeta, rows, rows_per_img, skip, accumulate) }
+  else { LN_DISPATCH(ln_bwd_kernel, float, (const float*)dy, x, mean, rstd, gamma, dresid, dx, (float*)dx_t, dgamma, dbeta, rows, rows_per_img, skip, accumulate) }
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_add_f32(const float* a, const float* b, float* out, void* out_t, int64_t n, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_add_f32");
+  S4F_CHECK(a && b && out && n > 0 && n % 4 == 0, "s4f_add_f32: bad args (n must be a multiple of 4)");
+  const int grid = grid_for(n / 4, 256);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, out, (bf16_t*)out_t, (long)n);
+  else hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, out, (float*)out_t, (long)n);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_ema(float* teacher, const float* student, void* teacher_t, int64_t n, float momentum,
+                    float one_minus_momentum, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_ema");
+  S4F_CHECK(teacher && student && n > 0, "s4f_ema: bad args");
+  S4F_CHECK(((uintptr_t)teacher % 16) == 0 && ((uintptr_t)student % 16) == 0, "s4f_ema: 16-B alignment");
+  const int grid = grid_for(n / 4 + 1, 256);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(ema_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, teacher, student, (bf16_t*)teacher_t, (long)n, momentum, one_minus_momentum);
+  else hipLaunchKernelGGL(ema_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, teacher, student, (float*)teacher_t, (long)n, momentum, one_minus_momentum);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_sgd_momentum(float* p, const float* g, float* buf, void* p_t, int64_t n, float lr, float momentum,
+                             float grad_scale, int first_step, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_sgd_momentum");
+  S4F_CHECK(p && g && buf && n > 0, "s4f_sgd_momentum: bad args");
+  S4F_CHECK(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)buf % 16) == 0, "s4f_sgd_momentum: 16-B alignment");
+  const int grid = grid_for(n / 4 + 1, 256);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(sgd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, buf, (bf16_t*)p_t, (long)n, lr, momentum, grad_scale, first_step);
+  else hipLaunchKernelGGL(sgd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, p, g, buf, (float*)p_t, (long)n, lr, momentum, grad_scale, first_step);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}

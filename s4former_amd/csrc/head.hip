@@ -1,0 +1,638 @@
+// Memory-bound kernels of the SETR-PUP head and the losses (channels-last activations):
+// BatchNorm statistics / finalize / fused BN+ReLU+bilinear-upsample forward and backward, fused
+// upsample+cross-entropy (forward and backward), teacher pseudo-labels, stand-alone CE.
+// Reference: setr_up_head.py:51-77,92-111; ops/wrappers.py:8-51; cross_entropy_loss.py:12-63;
+// encoder_decoder.py:888-901,906-934.  Bilinear rule (align_corners=False, integer scale s):
+//   src = (dst + 0.5)/s - 0.5, src < 0 -> 0, i0 = floor(src), i1 = min(i0+1, in-1), lam = src - i0.
+#include "common.h"
+#include "../../include/s4f.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 4096;
+inline int grid_for(long work_items, int per_block) {
+  long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > kMaxBlocks) b = kMaxBlocks;
+  return (int)b;
+}
+
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_src(int o, int s, int in) {
+  Lerp r;
+  if (s == 1) { r.i0 = o; r.i1 = o; r.l0 = 1.f; r.l1 = 0.f; return r; }
+  float src = ((float)o + 0.5f) / (float)s - 0.5f;
+  if (src < 0.f) src = 0.f;
+  r.i0 = (int)src;
+  r.i1 = r.i0 + 1 < in ? r.i0 + 1 : in - 1;
+  r.l1 = src - (float)r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+// weight with which output index o reads input index i
+__device__ __forceinline__ float lerp_w(int o, int i, int s, int in) {
+  const Lerp r = lerp_src(o, s, in);
+  return (r.i0 == i ? r.l0 : 0.f) + (r.i1 == i ? r.l1 : 0.f);
+}
+
+template <typename T> struct VT;                // 16-byte vector of T <-> floats
+template <> struct VT<bf16_t> {
+  static constexpr int N = 8;
+  __device__ static __forceinline__ void load(const bf16_t* p, float (&f)[8]) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = (float)v[e];
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float (&f)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)f[e];
+    *reinterpret_cast<bf16x8*>(p) = v;
+  }
+};
+template <> struct VT<float> {
+  static constexpr int N = 4;
+  __device__ static __forceinline__ void load(const float* p, float (&f)[4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) f[e] = v[e];
+  }
+  __device__ static __forceinline__ void store(float* p, const float (&f)[4]) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = f[e];
+    *reinterpret_cast<f32x4*>(p) = v;
+  }
+};
+
+// ------------------------------------------------------------------------------------------ BN statistics
+// thread -> (channel chunk cc = tid % CPR, row lane rl = tid / CPR); block covers rows_per_block rows
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, long rows, int C, float* __restrict__ sums,
+                                                       int rows_per_block) {
+  constexpr int N = VT<T>::N;
+  extern __shared__ float red[];          // [RL][2][C]
+  const int CPR = C / N;
+  const int RL = 256 / CPR;
+  const int cc = threadIdx.x % CPR, rl = threadIdx.x / CPR;
+  float s[N], q[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { s[e] = 0.f; q[e] = 0.f; }
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  for (long r = r0 + rl; r < r1; r += RL) {
+    float f[N];
+    VT<T>::load(x + r * C + cc * N, f);
+#pragma unroll
+    for (int e = 0; e < N; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    red[(rl * 2 + 0) * C + cc * N + e] = s[e];
+    red[(rl * 2 + 1) * C + cc * N + e] = q[e];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i % C;
+    float t = 0.f;
+    for (int k = 0; k < RL; ++k) t += red[(k * 2 + which) * C + c];
+    atomicAdd(sums + which * C + c, t);
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   float momentum, float eps, int training, float* __restrict__ scale,
+                                   float* __restrict__ shift, float* __restrict__ mean, float* __restrict__ rstd, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mu, var;
+  if (training) {
+    const double m = (double)sums[c] / count;
+    double v = (double)sums[C + c] / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mu = (float)m; var = (float)v;
+    if (rmean) {
+      const double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+      rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+      rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+  } else {
+    mu = rmean[c]; var = rvar[c];
+  }
+  const float rs = 1.f / sqrtf(var + eps);
+  const float sc = gamma[c] * rs;
+  scale[c] = sc;
+  shift[c] = beta[c] - mu * sc;
+  mean[c] = mu;
+  rstd[c] = rs;
+}
+
+// ------------------------------------------------------------------------------------------ BN + ReLU + upsample fwd
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_up_fwd_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, T* __restrict__ y, int B,
+                                                             int h, int w, int C, int s) {
+  constexpr int N = VT<T>::N;
+  const int CPR = C / N;
+  const int H = h * s, W = w * s;
+  const long total = (long)B * H * W * CPR;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cc = i % CPR;
+    long p = i / CPR;
+    const int ox = p % W; p /= W;
+    const int oy = p % H;
+    const int b = p / H;
+    float sc[N], sh[N], acc[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) { sc[e] = scale[cc * N + e]; sh[e] = shift[cc * N + e]; acc[e] = 0.f; }
+    const Lerp ly = lerp_src(oy, s, h), lx = lerp_src(ox, s, w);
+    const int ys[2] = {ly.i0, ly.i1}, xs[2] = {lx.i0, lx.i1};
+    const float wy[2] = {ly.l0, ly.l1}, wx[2] = {lx.l0, lx.l1};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c2 = 0; c2 < 2; ++c2) {
+        const float wgt = wy[a] * wx[c2];
+        if (wgt != 0.f) {
+          float f[N];
+          VT<T>::load(x + (((long)b * h + ys[a]) * w + xs[c2]) * C + cc * N, f);
+#pragma unroll
+          for (int e = 0; e < N; ++e) acc[e] += wgt * fmaxf(f[e] * sc[e] + sh[e], 0.f);
+        }
+      }
+    VT<T>::store(y + (((long)b * H + oy) * W + ox) * C + cc * N, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward, pass 1
+// g[b,i,j,c] = (sum over output pixels of w * dy) * [x*scale+shift > 0];  sums += (sum g, sum g*xhat)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_up_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             T* __restrict__ g, float* __restrict__ sums, int B, int h, int w,
+                                                             int C, int s) {
+  constexpr int N = VT<T>::N;
+  extern __shared__ float red[];          // [RL][2][C]
+  const int CPR = C / N;
+  const int RL = 256 / CPR;
+  const int cc = threadIdx.x % CPR, rl = threadIdx.x / CPR;
+  const int H = h * s, W = w * s;
+  float sc[N], sh[N], mu[N], rs[N], sg[N], sgx[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    sc[e] = scale[cc * N + e]; sh[e] = shift[cc * N + e]; mu[e] = mean[cc * N + e]; rs[e] = rstd[cc * N + e];
+    sg[e] = 0.f; sgx[e] = 0.f;
+  }
+  const long npix = (long)B * h * w;
+  for (long p = (long)blockIdx.x * RL + rl; p < npix; p += (long)gridDim.x * RL) {
+    const int j = p % w;
+    const long t = p / w;
+    const int i = t % h;
+    const int b = t / h;
+    float acc[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) acc[e] = 0.f;
+    if (s == 1) {
+      VT<T>::load(dy + p * C + cc * N, acc);
+    } else {
+      const int oy0 = max(0, s * i - s), oy1 = min(H - 1, s * i + 2 * s - 1);
+      const int ox0 = max(0, s * j - s), ox1 = min(W - 1, s * j + 2 * s - 1);
+      for (int oy = oy0; oy <= oy1; ++oy) {
+        const float wy = lerp_w(oy, i, s, h);
+        if (wy == 0.f) continue;
+        for (int ox = ox0; ox <= ox1; ++ox) {
+          const float wgt = wy * lerp_w(ox, j, s, w);
+          if (wgt == 0.f) continue;
+          float f[N];
+          VT<T>::load(dy + (((long)b * H + oy) * W + ox) * C + cc * N, f);
+#pragma unroll
+          for (int e = 0; e < N; ++e) acc[e] += wgt * f[e];
+        }
+      }
+    }
+    float xv[N];
+    VT<T>::load(x + p * C + cc * N, xv);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const float gg = (xv[e] * sc[e] + sh[e] > 0.f) ? acc[e] : 0.f;
+      acc[e] = gg;
+      sg[e] += gg;
+      sgx[e] += gg * (xv[e] - mu[e]) * rs[e];
+    }
+    VT<T>::store(g + p * C + cc * N, acc);
+  }
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    red[(rl * 2 + 0) * C + cc * N + e] = sg[e];
+    red[(rl * 2 + 1) * C + cc * N + e] = sgx[e];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * C; k += 256) {
+    const int which = k / C, c = k % C;
+    float t = 0.f;
+    for (int r = 0; r < RL; ++r) t += red[(r * 2 + which) * C + c];
+    atomicAdd(sums + which * C + c, t);
+  }
+}
+
+// pass 2: dx = gamma * rstd * (g - sum_g/n - xhat * sum_gx/n)
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sums,
+                                                           float inv_count, T* __restrict__ dx, long rows, int C) {
+  constexpr int N = VT<T>::N;
+  const int CPR = C / N;
+  const long total = rows * CPR;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int cc = i % CPR;
+    float gv[N], xv[N], o[N];
+    VT<T>::load(g + i * N, gv);
+    VT<T>::load(x + i * N, xv);
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+      const int c = cc * N + e;
+      const float xh = (xv[e] - mean[c]) * rstd[c];
+      o[e] = gamma[c] * rstd[c] * (gv[e] - sums[c] * inv_count - xh * sums[C + c] * inv_count);
+    }
+    VT<T>::store(dx + i * N, o);
+  }
+}
+
+__global__ void bn_param_grads_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] += sums[c];
+  dgamma[c] += sums[C + c];
+}
+
+// ------------------------------------------------------------------------------------------ upsampled logits helpers
+constexpr int kMaxC = 32;
+
+// z[c] = bilinear sample of logits_lo at output pixel (oy, ox)
+__device__ __forceinline__ void sample_logits(const float* __restrict__ lo, int b, int oy, int ox, int h, int w, int C,
+                                              int ldc, int s, float (&z)[kMaxC]) {
+  const Lerp ly = lerp_src(oy, s, h), lx = lerp_src(ox, s, w);
+  const float* p00 = lo + (((long)b * h + ly.i0) * w + lx.i0) * ldc;
+  const float* p01 = lo + (((long)b * h + ly.i0) * w + lx.i1) * ldc;
+  const float* p10 = lo + (((long)b * h + ly.i1) * w + lx.i0) * ldc;
+  const float* p11 = lo + (((long)b * h + ly.i1) * w + lx.i1) * ldc;
+  const float w00 = ly.l0 * lx.l0, w01 = ly.l0 * lx.l1, w10 = ly.l1 * lx.l0, w11 = ly.l1 * lx.l1;
+#pragma unroll
+  for (int c4 = 0; c4 < kMaxC / 4; ++c4) {
+    if (c4 * 4 < C) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + c4 * 4);
+      if (s == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[c4 * 4 + e] = a[e];
+      } else {
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(p01 + c4 * 4);
+        const f32x4 cq = *reinterpret_cast<const f32x4*>(p10 + c4 * 4);
+        const f32x4 dq = *reinterpret_cast<const f32x4*>(p11 + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[c4 * 4 + e] = w00 * a[e] + w01 * bq[e] + w10 * cq[e] + w11 * dq[e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[c4 * 4 + e] = 0.f;
+    }
+  }
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = wave_sum(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void upce_fwd_kernel(const float* __restrict__ lo, const uint8_t* __restrict__ labels,
+                                                       float* __restrict__ loss_sum, int B, int h, int w, int C, int ldc,
+                                                       int s, int ignore) {
+  __shared__ float red[4];
+  const int H = h * s, W = w * s;
+  const long total = (long)B * H * W;
+  const long stride = (long)gridDim.x * blockDim.x;
+  float lsum = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int lab = labels[i];
+    if (lab == ignore || lab >= C) continue;
+    const int ox = i % W;
+    const long t = i / W;
+    const int oy = t % H;
+    const int b = t / H;
+    float z[kMaxC];
+    sample_logits(lo, b, oy, ox, h, w, C, ldc, s, z);
+    float mx = -INFINITY, zl = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < C) { mx = fmaxf(mx, z[c]); zl = (c == lab) ? z[c] : zl; }
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < C) se += expf(z[c] - mx);
+    lsum += (mx + logf(se)) - zl;
+  }
+  const float tot = block_sum_256(lsum, red);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, tot);
+}
+
+// thread per low-res pixel: gathers w * gscale * (softmax - onehot) from every output pixel that reads it
+template <typename T>
+__global__ __launch_bounds__(256) void upce_bwd_kernel(const float* __restrict__ lo, const uint8_t* __restrict__ labels,
+                                                       float gscale, float* __restrict__ dlo, T* __restrict__ dlo_t, int B,
+                                                       int h, int w, int C, int ldc, int s, int ignore) {
+  const int H = h * s, W = w * s;
+  const long total = (long)B * h * w;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+    const int j = p % w;
+    const long t = p / w;
+    const int i = t % h;
+    const int b = t / h;
+    float acc[kMaxC];
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) acc[c] = 0.f;
+    const int oy0 = s == 1 ? i : max(0, s * i - s), oy1 = s == 1 ? i : min(H - 1, s * i + 2 * s - 1);
+    const int ox0 = s == 1 ? j : max(0, s * j - s), ox1 = s == 1 ? j : min(W - 1, s * j + 2 * s - 1);
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      const float wy = lerp_w(oy, i, s, h);
+      if (wy == 0.f) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        const float wgt = wy * lerp_w(ox, j, s, w);
+        if (wgt == 0.f) continue;
+        const int lab = labels[((long)b * H + oy) * W + ox];
+        if (lab == ignore || lab >= C) continue;
+        float z[kMaxC];
+        sample_logits(lo, b, oy, ox, h, w, C, ldc, s, z);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+          if (c < C) mx = fmaxf(mx, z[c]);
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+          if (c < C) { z[c] = expf(z[c] - mx); se += z[c]; }
+        const float k = wgt * gscale;
+        const float inv = k / se;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+          if (c < C) acc[c] += z[c] * inv - ((c == lab) ? k : 0.f);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < ldc) {
+        dlo[p * ldc + c] = acc[c];
+        if (dlo_t) dlo_t[p * ldc + c] = from_f32<T>(acc[c]);
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void up_pseudo_kernel(const float* __restrict__ lo, uint8_t* __restrict__ label_out,
+                                                        uint8_t* __restrict__ conf_out, unsigned long long* __restrict__ cnt,
+                                                        float th, int B, int h, int w, int C, int ldc, int s) {
+  __shared__ float red[4];
+  const int H = h * s, W = w * s;
+  const long total = (long)B * H * W;
+  const long stride = (long)gridDim.x * blockDim.x;
+  float nconf = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ox = i % W;
+    const long t = i / W;
+    const int oy = t % H;
+    const int b = t / H;
+    float z[kMaxC];
+    sample_logits(lo, b, oy, ox, h, w, C, ldc, s, z);
+    float mx = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < C && z[c] > mx) { mx = z[c]; am = c; }     // strict >: first index wins ties (torch.max)
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < C) se += expf(z[c] - mx);
+    const float pmax = 1.f / se;                         // = softmax(z)[argmax]: exp(0) / sum
+    const bool conf = pmax > th;
+    label_out[i] = conf ? (uint8_t)am : (uint8_t)255;
+    if (conf_out) conf_out[i] = conf ? 1 : 0;
+    nconf += conf ? 1.f : 0.f;
+  }
+  const float tot = block_sum_256(nconf, red);
+  if (threadIdx.x == 0 && cnt) atomicAdd(cnt, (unsigned long long)(tot + 0.5f));
+}
+
+__global__ __launch_bounds__(256) void up_logits_nchw_kernel(const float* __restrict__ lo, float* __restrict__ out, int B,
+                                                             int h, int w, int C, int ldc, int s) {
+  const int H = h * s, W = w * s;
+  const long total = (long)B * H * W;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int ox = i % W;
+    const long t = i / W;
+    const int oy = t % H;
+    const int b = t / H;
+    float z[kMaxC];
+    sample_logits(lo, b, oy, ox, h, w, C, ldc, s, z);
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < C) out[(((long)b * C + c) * H + oy) * W + ox] = z[c];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ stand-alone CE (NCHW / [N,C])
+__global__ void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                              const float* __restrict__ cw, float* __restrict__ loss, long N, int C, long spatial,
+                              int64_t ignore) {
+  const long total = N * spatial;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t lab = labels[i];
+    if (lab == ignore || lab < 0 || lab >= C) { loss[i] = 0.f; continue; }
+    const long n = i / spatial, sp = i % spatial;
+    const float* z = logits + n * C * spatial + sp;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c * spatial]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(z[c * spatial] - mx);
+    const float nll = (mx + logf(se)) - z[lab * spatial];
+    loss[i] = cw ? cw[lab] * nll : nll;
+  }
+}
+__global__ void ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                              const float* __restrict__ cw, const float* __restrict__ dloss, float* __restrict__ dlogits,
+                              long N, int C, long spatial, int64_t ignore) {
+  const long total = N * spatial;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t lab = labels[i];
+    const long n = i / spatial, sp = i % spatial;
+    const float* z = logits + n * C * spatial + sp;
+    float* dz = dlogits + n * C * spatial + sp;
+    if (lab == ignore || lab < 0 || lab >= C) {
+      for (int c = 0; c < C; ++c) dz[c * spatial] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c * spatial]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(z[c * spatial] - mx);
+    const float k = dloss[i] * (cw ? cw[lab] : 1.f);
+    for (int c = 0; c < C; ++c) dz[c * spatial] = k * (expf(z[c * spatial] - mx) / se - (c == lab ? 1.f : 0.f));
+  }
+}
+
+}  // namespace
+
+#define DT_CHECK(name) S4F_CHECK(dtype == S4F_F32 || dtype == S4F_BF16, name ": bad dtype %d", dtype)
+#define CH_CHECK(name)                                                                                              \
+  S4F_CHECK(C > 0 && C % (dtype == S4F_BF16 ? 8 : 4) == 0 && 256 % (C / (dtype == S4F_BF16 ? 8 : 4)) == 0 &&        \
+                C / (dtype == S4F_BF16 ? 8 : 4) <= 256,                                                             \
+            name ": unsupported channel count %d", C)
+
+S4F_API int s4f_bn_stats(const void* x, int64_t rows, int C, float* sums, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_bn_stats");
+  S4F_CHECK(x && sums && rows > 0, "s4f_bn_stats: bad args");
+  CH_CHECK("s4f_bn_stats");
+  const int cpr = C / (dtype == S4F_BF16 ? 8 : 4);
+  const int rl = 256 / cpr;
+  int rows_per_block = 256;
+  const int grid = ceil_div(rows, rows_per_block);
+  const size_t shm = (size_t)rl * 2 * C * sizeof(float);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)x, (long)rows, C, sums, rows_per_block);
+  else hipLaunchKernelGGL(bn_stats_kernel<float>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const float*)x, (long)rows, C, sums, rows_per_block);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_bn_finalize(const float* sums, double count, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float momentum, float eps, int training, float* scale, float* shift,
+                            float* mean, float* rstd, int C, s4f_stream stream) {
+  S4F_CHECK(gamma && beta && scale && shift && mean && rstd && C > 0, "s4f_bn_finalize: bad args");
+  S4F_CHECK(training ? (sums != nullptr && count > 0) : (running_mean && running_var), "s4f_bn_finalize: missing statistics");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, C);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_bn_relu_up_fwd(const void* x, const float* scale, const float* shift, void* y, int B, int h, int w, int C,
+                               int s, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_bn_relu_up_fwd");
+  S4F_CHECK(x && scale && shift && y && B > 0 && h > 0 && w > 0 && s >= 1, "s4f_bn_relu_up_fwd: bad args");
+  CH_CHECK("s4f_bn_relu_up_fwd");
+  const long total = (long)B * h * s * w * s * (C / (dtype == S4F_BF16 ? 8 : 4));
+  const int grid = grid_for(total, 256);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_relu_up_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, shift, (bf16_t*)y, B, h, w, C, s);
+  else hipLaunchKernelGGL(bn_relu_up_fwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)x, scale, shift, (float*)y, B, h, w, C, s);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_bn_relu_up_bwd(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
+                               const float* rstd, void* g, float* sums, int B, int h, int w, int C, int s, int dtype,
+                               s4f_stream stream) {
+  DT_CHECK("s4f_bn_relu_up_bwd");
+  S4F_CHECK(dy && x && scale && shift && mean && rstd && g && sums && B > 0 && h > 0 && w > 0 && s >= 1, "s4f_bn_relu_up_bwd: bad args");
+  CH_CHECK("s4f_bn_relu_up_bwd");
+  const int cpr = C / (dtype == S4F_BF16 ? 8 : 4);
+  const int rl = 256 / cpr;
+  const long npix = (long)B * h * w;
+  int grid = grid_for(npix, rl * 4);
+  const size_t shm = (size_t)rl * 2 * C * sizeof(float);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_relu_up_bwd_kernel<bf16_t>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, rstd, (bf16_t*)g, sums, B, h, w, C, s);
+  else hipLaunchKernelGGL(bn_relu_up_bwd_kernel<float>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const float*)dy, (const float*)x, scale, shift, mean, rstd, (float*)g, sums, B, h, w, C, s);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_bn_bwd_apply(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma,
+                             const float* sums, double count, void* dx, int64_t rows, int C, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_bn_bwd_apply");
+  S4F_CHECK(g && x && mean && rstd && gamma && sums && dx && rows > 0 && count > 0, "s4f_bn_bwd_apply: bad args");
+  CH_CHECK("s4f_bn_bwd_apply");
+  const long total = rows * (C / (dtype == S4F_BF16 ? 8 : 4));
+  const int grid = grid_for(total, 256);
+  const float inv = (float)(1.0 / count);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)x, mean, rstd, gamma, sums, inv, (bf16_t*)dx, (long)rows, C);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)x, mean, rstd, gamma, sums, inv, (float*)dx, (long)rows, C);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_bn_param_grads(const float* sums_local, float* dgamma, float* dbeta, int C, s4f_stream stream) {
+  S4F_CHECK(sums_local && dgamma && dbeta && C > 0, "s4f_bn_param_grads: bad args");
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums_local, dgamma, dbeta, C);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+#define LOGIT_CHECK(name)                                                                                   \
+  S4F_CHECK(B > 0 && h > 0 && w > 0 && s >= 1 && C > 0 && C <= 32 && ldc >= C && ldc % 4 == 0 && ldc <= 32, \
+            name ": bad geometry (C=%d ldc=%d s=%d)", C, ldc, s)
+
+S4F_API int s4f_upce_fwd(const float* logits_lo, const uint8_t* labels, float* loss_sum, int B, int h, int w, int C, int ldc,
+                         int s, int ignore_index, s4f_stream stream) {
+  S4F_CHECK(logits_lo && labels && loss_sum, "s4f_upce_fwd: null pointer");
+  LOGIT_CHECK("s4f_upce_fwd");
+  const long total = (long)B * h * s * w * s;
+  hipLaunchKernelGGL(upce_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, loss_sum, B, h, w, C, ldc, s, ignore_index);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, float gscale, float* dlo, void* dlo_t, int B, int h,
+                         int w, int C, int ldc, int s, int ignore_index, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_upce_bwd");
+  S4F_CHECK(logits_lo && labels && dlo, "s4f_upce_bwd: null pointer");
+  LOGIT_CHECK("s4f_upce_bwd");
+  const long total = (long)B * h * w;
+  const int grid = grid_for(total, 256);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(upce_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, gscale, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, s, ignore_index);
+  else hipLaunchKernelGGL(upce_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, gscale, dlo, (float*)dlo_t, B, h, w, C, ldc, s, ignore_index);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_up_pseudo_label(const float* logits_lo, uint8_t* label_out, uint8_t* conf_out, unsigned long long* conf_count,
+                                float th, int B, int h, int w, int C, int ldc, int s, s4f_stream stream) {
+  S4F_CHECK(logits_lo && label_out, "s4f_up_pseudo_label: null pointer");
+  LOGIT_CHECK("s4f_up_pseudo_label");
+  const long total = (long)B * h * s * w * s;
+  hipLaunchKernelGGL(up_pseudo_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, logits_lo, label_out, conf_out, conf_count, th, B, h, w, C, ldc, s);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_up_logits_nchw(const float* logits_lo, float* out, int B, int h, int w, int C, int ldc, int s, s4f_stream stream) {
+  S4F_CHECK(logits_lo && out, "s4f_up_logits_nchw: null pointer");
+  LOGIT_CHECK("s4f_up_logits_nchw");
+  const long total = (long)B * h * s * w * s;
+  hipLaunchKernelGGL(up_logits_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, logits_lo, out, B, h, w, C, ldc, s);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_ce_fwd(const float* logits, const int64_t* labels, const float* class_weight, float* loss_elem, int64_t N,
+                       int C, int64_t spatial, int64_t ignore_index, s4f_stream stream) {
+  S4F_CHECK(logits && labels && loss_elem && N > 0 && C > 0 && spatial > 0, "s4f_ce_fwd: bad args");
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(grid_for(N * spatial, 256)), dim3(256), 0, (hipStream_t)stream, logits, labels, class_weight, loss_elem, (long)N, C, (long)spatial, ignore_index);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_ce_bwd(const float* logits, const int64_t* labels, const float* class_weight, const float* dloss_elem,
+                       float* dlogits, int64_t N, int C, int64_t spatial, int64_t ignore_index, s4f_stream stream) {
+  S4F_CHECK(logits && labels && dloss_elem && dlogits && N > 0 && C > 0 && spatial > 0, "s4f_ce_bwd: bad args");
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(grid_for(N * spatial, 256)), dim3(256), 0, (hipStream_t)stream, logits, labels, class_weight, dloss_elem, dlogits, (long)N, C, (long)spatial, ignore_index);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}

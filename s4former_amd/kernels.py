@@ -1,0 +1,328 @@
+"""Typed Python front of the C ABI: one function per kernel family, host-side shape/extent validation
+(every operand extent is checked against what the kernel's grid will touch before anything is launched),
+raw pointers + current stream passed through ctypes.  No torch math here."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from ._lib import (ACT_GELU, ACT_GELU_BWD, ACT_NONE, BF16, F32, OP_K, OP_K_CONV, OP_K_TAPSPLIT, OP_ROW,
+                   OP_ROW_CONV, S4FError, call, p, stream)
+
+__all__ = ['gemm', 'cast', 'cast_back', 'im2col_patch16', 'cls_pos', 'tokens_bwd', 'colsum', 'layernorm_fwd',
+           'layernorm_bwd', 'add_f32', 'attention_fwd', 'attention_bwd', 'bn_stats', 'bn_finalize',
+           'bn_relu_up_fwd', 'bn_relu_up_bwd', 'bn_bwd_apply', 'bn_param_grads', 'upce_fwd', 'upce_bwd',
+           'up_pseudo_label', 'up_logits_nchw', 'ce_fwd', 'ce_bwd', 'ema', 'sgd_momentum']
+
+
+def _need(t, n, what):
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise S4FError(f'{what}: expected a device tensor')
+    if not t.is_contiguous():
+        raise S4FError(f'{what}: tensor must be contiguous')
+    if t.numel() < n:
+        raise S4FError(f'{what}: tensor has {t.numel()} elements, kernel touches {n}')
+
+
+def _tdt(code):
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def _chk_dtype(t, code, what):
+    if t is not None and t.dtype != _tdt(code):
+        raise S4FError(f'{what}: dtype {t.dtype} != {_tdt(code)}')
+
+
+def _chk_f32(t, what):
+    if t is not None and t.dtype != torch.float32:
+        raise S4FError(f'{what}: must be float32, got {t.dtype}')
+
+
+def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=1.0, bias=None, resid=None, ldr=0,
+         out_f32=None, ldo_f32=0, out_t=None, ldo_t=0, out_pre=None, ldo_pre=0, aux=None, ld_aux=0, act=ACT_NONE,
+         atomic=False, splitk=1, conv=None, rowmap_tpi=0, pos=None):
+    """C[m,n] = alpha * sum_k A(m,k) B(n,k) + epilogue; see include/s4f.h. conv = (B, H, W, C, sign)."""
+    _chk_dtype(A, dtype, 'gemm A'); _chk_dtype(B, dtype, 'gemm B')
+    _chk_dtype(out_t, dtype, 'gemm out_t'); _chk_dtype(out_pre, dtype, 'gemm out_pre'); _chk_dtype(aux, dtype, 'gemm aux')
+    _chk_f32(bias, 'gemm bias'); _chk_f32(resid, 'gemm resid'); _chk_f32(out_f32, 'gemm out_f32'); _chk_f32(pos, 'gemm pos')
+    cB = cH = cW = cC = 0
+    csign = 1
+    if conv is not None:
+        cB, cH, cW, cC, csign = conv
+    # operand extents
+    if a_mode == OP_ROW:
+        _need(A, (M - 1) * lda + K, 'gemm A')
+    elif a_mode == OP_K:
+        _need(A, (K - 1) * lda + M, 'gemm A')
+    elif a_mode == OP_ROW_CONV:
+        _need(A, (cB * cH * cW - 1) * lda + cC, 'gemm A (conv)')
+    else:
+        raise S4FError(f'bad a_mode {a_mode}')
+    if b_mode == OP_ROW:
+        _need(B, (N - 1) * ldb + K, 'gemm B')
+    elif b_mode == OP_K:
+        _need(B, (K - 1) * ldb + N, 'gemm B')
+    elif b_mode == OP_K_TAPSPLIT:
+        _need(B, (cC - 1) * ldb + 9 * N, 'gemm B (tapsplit)')
+    elif b_mode == OP_K_CONV:
+        _need(B, (cB * cH * cW - 1) * ldb + cC, 'gemm B (conv)')
+    else:
+        raise S4FError(f'bad b_mode {b_mode}')
+    rows_out = M if rowmap_tpi == 0 else M + (M + rowmap_tpi - 1) // rowmap_tpi
+    if rowmap_tpi and M % rowmap_tpi:
+        raise S4FError('gemm: M must be a multiple of rowmap_tpi')
+    _need(bias, N, 'gemm bias')
+    _need(out_f32, (rows_out - 1) * ldo_f32 + N if out_f32 is not None else 0, 'gemm out_f32')
+    _need(out_t, (rows_out - 1) * ldo_t + N if out_t is not None else 0, 'gemm out_t')
+    _need(out_pre, (rows_out - 1) * ldo_pre + N if out_pre is not None else 0, 'gemm out_pre')
+    _need(resid, (rows_out - 1) * ldr + N if resid is not None else 0, 'gemm resid')
+    _need(aux, (M - 1) * ld_aux + N if aux is not None else 0, 'gemm aux')
+    _need(pos, (rowmap_tpi + 1) * N if pos is not None else 0, 'gemm pos')
+    d = L.GemmDesc()
+    d.A, d.B = p(A), p(B)
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb = lda, ldb
+    d.a_mode, d.b_mode, d.dtype, d.splitk = a_mode, b_mode, dtype, max(1, int(splitk))
+    d.cB, d.cH, d.cW, d.cC, d.csign = cB, cH, cW, cC, csign
+    d.alpha = alpha
+    d.bias, d.resid, d.ldr = p(bias), p(resid), ldr
+    d.out_f32, d.ldo_f32 = p(out_f32), ldo_f32
+    d.out_t, d.ldo_t = p(out_t), ldo_t
+    d.out_pre, d.ldo_pre = p(out_pre), ldo_pre
+    d.aux, d.ld_aux = p(aux), ld_aux
+    d.act, d.atomic = act, 1 if atomic else 0
+    d.rowmap_tpi, d.pos = rowmap_tpi, p(pos)
+    call('s4f_gemm', ctypes.byref(d), stream())
+
+
+def cast(src, dst, dtype):
+    _chk_f32(src, 'cast src'); _chk_dtype(dst, dtype, 'cast dst')
+    _need(src, dst.numel(), 'cast src'); _need(dst, src.numel(), 'cast dst')
+    call('s4f_cast', p(src), p(dst), src.numel(), dtype, stream())
+
+
+def cast_back(src, dst, dtype):
+    _chk_f32(dst, 'cast_back dst'); _chk_dtype(src, dtype, 'cast_back src')
+    _need(src, dst.numel(), 'cast_back src'); _need(dst, src.numel(), 'cast_back dst')
+    call('s4f_cast_back', p(src), p(dst), src.numel(), dtype, stream())
+
+
+def im2col_patch16(img, cols, dtype):
+    B, Cin, H, W = img.shape
+    if Cin != 3:
+        raise S4FError('im2col_patch16: 3 input channels expected')
+    _chk_f32(img, 'im2col img'); _chk_dtype(cols, dtype, 'im2col cols')
+    _need(img, B * 3 * H * W, 'im2col img'); _need(cols, B * (H // 16) * (W // 16) * 768, 'im2col cols')
+    call('s4f_im2col_patch16', p(img), p(cols), B, H, W, dtype, stream())
+
+
+def cls_pos(cls, pos, tokens):
+    B, ntok, C = tokens.shape
+    for t, n in ((cls, C), (pos, ntok * C), (tokens, B * ntok * C)):
+        _chk_f32(t, 'cls_pos'); _need(t, n, 'cls_pos')
+    call('s4f_cls_pos', p(cls), p(pos), p(tokens), B, ntok, C, stream())
+
+
+def tokens_bwd(dtok, dpos, dcls):
+    B, ntok, C = dtok.shape
+    for t, n in ((dcls, C), (dpos, ntok * C), (dtok, B * ntok * C)):
+        _chk_f32(t, 'tokens_bwd'); _need(t, n, 'tokens_bwd')
+    call('s4f_tokens_bwd', p(dtok), p(dpos), p(dcls), B, ntok, C, stream())
+
+
+def colsum(X, ld, M, N, out, dtype):
+    _chk_dtype(X, dtype, 'colsum X'); _chk_f32(out, 'colsum out')
+    _need(X, (M - 1) * ld + N, 'colsum X'); _need(out, N, 'colsum out')
+    call('s4f_colsum', p(X), ld, M, N, p(out), dtype, stream())
+
+
+def _ln_in_rows(rows, rows_per_img, skip):
+    return rows + (rows // rows_per_img) * skip if skip else rows
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, dtype, eps, rows_per_img=0, skip=0):
+    if skip and rows % rows_per_img:
+        raise S4FError('layernorm_fwd: rows must be a multiple of rows_per_img')
+    _chk_f32(x, 'ln x'); _chk_f32(gamma, 'ln gamma'); _chk_f32(beta, 'ln beta'); _chk_dtype(y, dtype, 'ln y')
+    _chk_f32(mean, 'ln mean'); _chk_f32(rstd, 'ln rstd')
+    _need(x, _ln_in_rows(rows, rows_per_img, skip) * C, 'ln x'); _need(y, rows * C, 'ln y')
+    _need(gamma, C, 'ln gamma'); _need(beta, C, 'ln beta'); _need(mean, rows, 'ln mean'); _need(rstd, rows, 'ln rstd')
+    call('s4f_layernorm_fwd', p(x), p(gamma), p(beta), p(y), p(mean), p(rstd), rows, C, rows_per_img, skip, eps, dtype,
+         stream())
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dresid, dx, dx_t, dgamma, dbeta, rows, C, dtype, rows_per_img=0, skip=0,
+                  accumulate=False):
+    if skip and rows % rows_per_img:
+        raise S4FError('layernorm_bwd: rows must be a multiple of rows_per_img')
+    nin = _ln_in_rows(rows, rows_per_img, skip) * C
+    _chk_dtype(dy, dtype, 'ln_bwd dy'); _chk_dtype(dx_t, dtype, 'ln_bwd dx_t')
+    for t in (x, mean, rstd, gamma, dresid, dx, dgamma, dbeta):
+        _chk_f32(t, 'ln_bwd')
+    _need(dy, rows * C, 'ln_bwd dy'); _need(x, nin, 'ln_bwd x'); _need(dx, nin, 'ln_bwd dx')
+    _need(dresid, nin if dresid is not None else 0, 'ln_bwd dresid')
+    _need(dx_t, nin if dx_t is not None else 0, 'ln_bwd dx_t')
+    _need(mean, rows, 'ln_bwd mean'); _need(rstd, rows, 'ln_bwd rstd')
+    _need(gamma, C, 'ln_bwd gamma'); _need(dgamma, C, 'ln_bwd dgamma'); _need(dbeta, C, 'ln_bwd dbeta')
+    call('s4f_layernorm_bwd', p(dy), p(x), p(mean), p(rstd), p(gamma), p(dresid), p(dx), p(dx_t), p(dgamma), p(dbeta),
+         rows, C, rows_per_img, skip, 1 if accumulate else 0, dtype, stream())
+
+
+def add_f32(a, b, out, out_t, dtype):
+    n = a.numel()
+    for t in (a, b, out):
+        _chk_f32(t, 'add_f32'); _need(t, n, 'add_f32')
+    _chk_dtype(out_t, dtype, 'add_f32 out_t'); _need(out_t, n if out_t is not None else 0, 'add_f32 out_t')
+    call('s4f_add_f32', p(a), p(b), p(out), p(out_t), n, dtype, stream())
+
+
+def attention_fwd(qkv, ctx, lse, B, N, H, dtype, bias_u=None, row_flag=None, bias_w=0.0):
+    _chk_dtype(qkv, dtype, 'attn qkv'); _chk_dtype(ctx, dtype, 'attn ctx'); _chk_f32(lse, 'attn lse')
+    _chk_f32(bias_u, 'attn bias_u'); _chk_f32(row_flag, 'attn row_flag')
+    _need(qkv, B * N * 3 * H * 64, 'attn qkv'); _need(ctx, B * N * H * 64, 'attn ctx'); _need(lse, B * H * N, 'attn lse')
+    _need(bias_u, B * N if bias_u is not None else 0, 'attn bias_u')
+    _need(row_flag, B * N if row_flag is not None else 0, 'attn row_flag')
+    call('s4f_attention_fwd', p(qkv), p(ctx), p(lse), p(bias_u), p(row_flag), bias_w, B, N, H, dtype, stream())
+
+
+def attention_bwd(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, dtype, bias_u=None, row_flag=None, bias_w=0.0):
+    for t, w in ((qkv, 'qkv'), (ctx, 'ctx'), (dctx, 'dctx'), (dqkv, 'dqkv')):
+        _chk_dtype(t, dtype, 'attn_bwd ' + w)
+    for t in (lse, delta, bias_u, row_flag):
+        _chk_f32(t, 'attn_bwd')
+    _need(qkv, B * N * 3 * H * 64, 'attn_bwd qkv'); _need(dqkv, B * N * 3 * H * 64, 'attn_bwd dqkv')
+    _need(ctx, B * N * H * 64, 'attn_bwd ctx'); _need(dctx, B * N * H * 64, 'attn_bwd dctx')
+    _need(lse, B * H * N, 'attn_bwd lse'); _need(delta, B * H * N, 'attn_bwd delta')
+    _need(bias_u, B * N if bias_u is not None else 0, 'attn_bwd bias_u')
+    _need(row_flag, B * N if row_flag is not None else 0, 'attn_bwd row_flag')
+    call('s4f_attention_bwd', p(qkv), p(ctx), p(dctx), p(lse), p(delta), p(dqkv), p(bias_u), p(row_flag), bias_w, B, N,
+         H, dtype, stream())
+
+
+def bn_stats(x, rows, C, sums, dtype):
+    _chk_dtype(x, dtype, 'bn_stats x'); _chk_f32(sums, 'bn_stats sums')
+    _need(x, rows * C, 'bn_stats x'); _need(sums, 2 * C, 'bn_stats sums')
+    call('s4f_bn_stats', p(x), rows, C, p(sums), dtype, stream())
+
+
+def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd, C):
+    for t in (sums, gamma, beta, running_mean, running_var, scale, shift, mean, rstd):
+        _chk_f32(t, 'bn_finalize')
+    _need(sums, 2 * C if sums is not None else 0, 'bn_finalize sums')
+    for t in (gamma, beta, running_mean, running_var, scale, shift, mean, rstd):
+        _need(t, C if t is not None else 0, 'bn_finalize')
+    call('s4f_bn_finalize', p(sums), float(count), p(gamma), p(beta), p(running_mean), p(running_var), momentum, eps,
+         1 if training else 0, p(scale), p(shift), p(mean), p(rstd), C, stream())
+
+
+def bn_relu_up_fwd(x, scale, shift, y, B, h, w, C, s, dtype):
+    _chk_dtype(x, dtype, 'bn_relu_up x'); _chk_dtype(y, dtype, 'bn_relu_up y')
+    _chk_f32(scale, 'bn_relu_up scale'); _chk_f32(shift, 'bn_relu_up shift')
+    _need(x, B * h * w * C, 'bn_relu_up x'); _need(y, B * h * s * w * s * C, 'bn_relu_up y')
+    _need(scale, C, 'bn_relu_up scale'); _need(shift, C, 'bn_relu_up shift')
+    call('s4f_bn_relu_up_fwd', p(x), p(scale), p(shift), p(y), B, h, w, C, s, dtype, stream())
+
+
+def bn_relu_up_bwd(dy, x, scale, shift, mean, rstd, g, sums, B, h, w, C, s, dtype):
+    _chk_dtype(dy, dtype, 'bn_relu_up_bwd dy'); _chk_dtype(x, dtype, 'bn_relu_up_bwd x'); _chk_dtype(g, dtype, 'bn_relu_up_bwd g')
+    for t in (scale, shift, mean, rstd):
+        _chk_f32(t, 'bn_relu_up_bwd'); _need(t, C, 'bn_relu_up_bwd')
+    _chk_f32(sums, 'bn_relu_up_bwd sums'); _need(sums, 2 * C, 'bn_relu_up_bwd sums')
+    _need(dy, B * h * s * w * s * C, 'bn_relu_up_bwd dy'); _need(x, B * h * w * C, 'bn_relu_up_bwd x')
+    _need(g, B * h * w * C, 'bn_relu_up_bwd g')
+    call('s4f_bn_relu_up_bwd', p(dy), p(x), p(scale), p(shift), p(mean), p(rstd), p(g), p(sums), B, h, w, C, s, dtype,
+         stream())
+
+
+def bn_bwd_apply(g, x, mean, rstd, gamma, sums, count, dx, rows, C, dtype):
+    _chk_dtype(g, dtype, 'bn_bwd_apply g'); _chk_dtype(x, dtype, 'bn_bwd_apply x'); _chk_dtype(dx, dtype, 'bn_bwd_apply dx')
+    for t in (mean, rstd, gamma):
+        _chk_f32(t, 'bn_bwd_apply'); _need(t, C, 'bn_bwd_apply')
+    _chk_f32(sums, 'bn_bwd_apply sums'); _need(sums, 2 * C, 'bn_bwd_apply sums')
+    for t in (g, x, dx):
+        _need(t, rows * C, 'bn_bwd_apply')
+    call('s4f_bn_bwd_apply', p(g), p(x), p(mean), p(rstd), p(gamma), p(sums), float(count), p(dx), rows, C, dtype, stream())
+
+
+def bn_param_grads(sums_local, dgamma, dbeta, C):
+    for t, n in ((sums_local, 2 * C), (dgamma, C), (dbeta, C)):
+        _chk_f32(t, 'bn_param_grads'); _need(t, n, 'bn_param_grads')
+    call('s4f_bn_param_grads', p(sums_local), p(dgamma), p(dbeta), C, stream())
+
+
+def _chk_u8(t, n, what):
+    if t is None:
+        return
+    if t.dtype != torch.uint8:
+        raise S4FError(f'{what}: must be uint8')
+    _need(t, n, what)
+
+
+def upce_fwd(logits_lo, labels, loss_sum, B, h, w, C, ldc, s, ignore_index=255):
+    _chk_f32(logits_lo, 'upce logits'); _need(logits_lo, B * h * w * ldc, 'upce logits')
+    _chk_u8(labels, B * h * s * w * s, 'upce labels'); _chk_f32(loss_sum, 'upce loss'); _need(loss_sum, 1, 'upce loss')
+    call('s4f_upce_fwd', p(logits_lo), p(labels), p(loss_sum), B, h, w, C, ldc, s, ignore_index, stream())
+
+
+def upce_bwd(logits_lo, labels, gscale, dlo, dlo_t, B, h, w, C, ldc, s, dtype, ignore_index=255):
+    _chk_f32(logits_lo, 'upce_bwd logits'); _need(logits_lo, B * h * w * ldc, 'upce_bwd logits')
+    _chk_u8(labels, B * h * s * w * s, 'upce_bwd labels')
+    _chk_f32(dlo, 'upce_bwd dlo'); _need(dlo, B * h * w * ldc, 'upce_bwd dlo')
+    _chk_dtype(dlo_t, dtype, 'upce_bwd dlo_t'); _need(dlo_t, B * h * w * ldc if dlo_t is not None else 0, 'upce_bwd dlo_t')
+    call('s4f_upce_bwd', p(logits_lo), p(labels), float(gscale), p(dlo), p(dlo_t), B, h, w, C, ldc, s, ignore_index,
+         dtype, stream())
+
+
+def up_pseudo_label(logits_lo, label_out, conf_out, conf_count, th, B, h, w, C, ldc, s):
+    _chk_f32(logits_lo, 'pseudo logits'); _need(logits_lo, B * h * w * ldc, 'pseudo logits')
+    _chk_u8(label_out, B * h * s * w * s, 'pseudo labels'); _chk_u8(conf_out, B * h * s * w * s, 'pseudo conf')
+    if conf_count is not None and (conf_count.dtype != torch.int64 or conf_count.numel() < 1):
+        raise S4FError('pseudo conf_count must be an int64 tensor')
+    call('s4f_up_pseudo_label', p(logits_lo), p(label_out), p(conf_out), p(conf_count), float(np.float32(th)), B, h, w,
+         C, ldc, s, stream())
+
+
+def up_logits_nchw(logits_lo, out, B, h, w, C, ldc, s):
+    _chk_f32(logits_lo, 'up_logits lo'); _need(logits_lo, B * h * w * ldc, 'up_logits lo')
+    _chk_f32(out, 'up_logits out'); _need(out, B * C * h * s * w * s, 'up_logits out')
+    call('s4f_up_logits_nchw', p(logits_lo), p(out), B, h, w, C, ldc, s, stream())
+
+
+def ce_fwd(logits, labels, class_weight, loss_elem, N, C, spatial, ignore_index):
+    _chk_f32(logits, 'ce logits'); _need(logits, N * C * spatial, 'ce logits')
+    if labels.dtype != torch.int64:
+        raise S4FError('ce labels must be int64')
+    _need(labels, N * spatial, 'ce labels'); _chk_f32(loss_elem, 'ce loss'); _need(loss_elem, N * spatial, 'ce loss')
+    _chk_f32(class_weight, 'ce class_weight'); _need(class_weight, C if class_weight is not None else 0, 'ce class_weight')
+    call('s4f_ce_fwd', p(logits), p(labels), p(class_weight), p(loss_elem), N, C, spatial, ignore_index, stream())
+
+
+def ce_bwd(logits, labels, class_weight, dloss_elem, dlogits, N, C, spatial, ignore_index):
+    _chk_f32(logits, 'ce_bwd logits'); _need(logits, N * C * spatial, 'ce_bwd logits')
+    _chk_f32(dlogits, 'ce_bwd dlogits'); _need(dlogits, N * C * spatial, 'ce_bwd dlogits')
+    if labels.dtype != torch.int64:
+        raise S4FError('ce labels must be int64')
+    _need(labels, N * spatial, 'ce_bwd labels'); _chk_f32(dloss_elem, 'ce_bwd dloss'); _need(dloss_elem, N * spatial, 'ce_bwd dloss')
+    _chk_f32(class_weight, 'ce class_weight'); _need(class_weight, C if class_weight is not None else 0, 'ce class_weight')
+    call('s4f_ce_bwd', p(logits), p(labels), p(class_weight), p(dloss_elem), p(dlogits), N, C, spatial, ignore_index,
+         stream())
+
+
+def ema(teacher, student, teacher_t, n, momentum, dtype):
+    """momentum is the Python float of the reference; both fp32 scalars are derived as torch derives them."""
+    _chk_f32(teacher, 'ema teacher'); _chk_f32(student, 'ema student'); _chk_dtype(teacher_t, dtype, 'ema teacher_t')
+    _need(teacher, n, 'ema teacher'); _need(student, n, 'ema student')
+    _need(teacher_t, n if teacher_t is not None else 0, 'ema teacher_t')
+    call('s4f_ema', p(teacher), p(student), p(teacher_t), n, float(np.float32(momentum)),
+         float(np.float32(1 - momentum)), dtype, stream())
+
+
+def sgd_momentum(param, grad, buf, param_t, n, lr, momentum, grad_scale, first_step, dtype):
+    for t in (param, grad, buf):
+        _chk_f32(t, 'sgd'); _need(t, n, 'sgd')
+    _chk_dtype(param_t, dtype, 'sgd param_t'); _need(param_t, n if param_t is not None else 0, 'sgd param_t')
+    call('s4f_sgd_momentum', p(param), p(grad), p(buf), p(param_t), n, float(np.float32(lr)), float(np.float32(momentum)),
+         float(np.float32(grad_scale)), 1 if first_step else 0, dtype, stream())

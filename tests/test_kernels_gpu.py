@@ -1,0 +1,463 @@
+"""GPU parity tests of every kernel family behind the C ABI against the CPU oracle (oracle/ops.py).
+
+Both numeric modes are exercised: S4F_F32 (parity mode, tolerance 1e-4 relative to the tensor's max magnitude —
+the tolerance BASELINE.json's north_star states for fp32 losses/grads) and S4F_BF16 (perf mode, 3e-2: bf16 has
+8 significand bits).  Integer outputs (pseudo labels, confidence masks) must be bit-exact.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {0: 1e-4, 1: 3e-2}
+DTYPES = [0, 1]
+
+
+@pytest.fixture(scope='module')
+def K():
+    from s4former_amd import kernels
+    return kernels
+
+
+def tdt(code):
+    return torch.bfloat16 if code == 1 else torch.float32
+
+
+def dev(t, code=None):
+    t = t.contiguous()
+    if code is not None and t.dtype.is_floating_point:
+        t = t.to(tdt(code))
+    return t.cuda()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def q(t, code):
+    """quantise a CPU fp32 tensor to the operand type (so the oracle sees exactly what the kernel sees)"""
+    return t.to(tdt(code)).float()
+
+
+def check(got, ref, code, what, tol=None):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float()
+    assert got.shape == ref.shape, f'{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}'
+    assert torch.isfinite(got).all(), f'{what}: non-finite values'
+    scale = ref.abs().max().item() + 1e-30
+    err = (got - ref).abs().max().item() / scale
+    tol = TOL[code] if tol is None else tol
+    assert err <= tol, f'{what}: max rel-to-scale error {err:.3e} > {tol:.1e} (scale {scale:.3e})'
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('code', DTYPES)
+@pytest.mark.parametrize('M,N,K_', [(197, 768, 768), (130, 100, 64), (2050, 256, 3072), (64, 21, 256)])
+def test_gemm_nt_bias(K, code, M, N, K_):
+    x, w, b = q(rnd(M, K_, seed=1), code), q(rnd(N, K_, seed=2, scale=0.05), code), rnd(N, seed=3)
+    ref = O.linear(x, w, b)
+    out = torch.empty(M, N, device='cuda')
+    out_t = torch.empty(M, N, device='cuda', dtype=tdt(code))
+    K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), out_f32=out, ldo_f32=N, out_t=out_t, ldo_t=N)
+    check(out, ref, code, 'gemm NT fp32 out')
+    check(out_t, ref, code, 'gemm NT T out', tol=max(TOL[code], 1e-2 if code else 1e-4))
+
+
+@pytest.mark.parametrize('code', DTYPES)
+def test_gemm_nt_gelu_resid(K, code):
+    M, N, K_ = 197, 3072, 768
+    x, w, b = q(rnd(M, K_, seed=1), code), q(rnd(N, K_, seed=2, scale=0.05), code), rnd(N, seed=3)
+    z = O.linear(x, w, b)
+    a = O.gelu(z)
+    out_t = torch.empty(M, N, device='cuda', dtype=tdt(code))
+    out_pre = torch.empty(M, N, device='cuda', dtype=tdt(code))
+    K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), out_t=out_t, ldo_t=N, out_pre=out_pre,
+           ldo_pre=N, act=K.ACT_GELU)
+    check(out_pre, z, code, 'gelu pre-activation')
+    check(out_t, a, code, 'gelu output')
+    # residual epilogue: y = resid + x2 w2^T + b2
+    M, N, K_ = 197, 768, 3072
+    x2, w2, b2, r = q(rnd(M, K_, seed=4), code), q(rnd(N, K_, seed=5, scale=0.02), code), rnd(N, seed=6), rnd(M, N, seed=7)
+    ref = r + O.linear(x2, w2, b2)
+    out = torch.empty(M, N, device='cuda')
+    K.gemm(dev(x2, code), dev(w2, code), M, N, K_, K_, K_, code, bias=dev(b2), resid=dev(r), ldr=N, out_f32=out, ldo_f32=N)
+    check(out, ref, code, 'residual epilogue')
+
+
+@pytest.mark.parametrize('code', DTYPES)
+def test_gemm_gelu_bwd(K, code):
+    M, N, K_ = 130, 3072, 768     # da = dy W2 (NN), dz = da * gelu'(z)
+    dy, w2 = q(rnd(M, K_, seed=1), code), q(rnd(K_, N, seed=2, scale=0.05), code)   # w2 [768, 3072]
+    zz = q(rnd(M, N, seed=3, scale=2.0), code)
+    zr = zz.clone().requires_grad_(True)
+    O.gelu(zr).backward(dy @ w2)
+    out_t = torch.empty(M, N, device='cuda', dtype=tdt(code))
+    K.gemm(dev(dy, code), dev(w2, code), M, N, K_, K_, N, code, b_mode=K.OP_K, out_t=out_t, ldo_t=N, aux=dev(zz, code),
+           ld_aux=N, act=K.ACT_GELU_BWD)
+    check(out_t, zr.grad, code, 'gelu backward epilogue')
+
+
+@pytest.mark.parametrize('code', DTYPES)
+@pytest.mark.parametrize('M,N,K_', [(197, 768, 2304), (130, 64, 100), (1030, 3072, 768)])
+def test_gemm_nn(K, code, M, N, K_):
+    # dx[M,N] = dy[M,K] W[K,N]   (B in k-major mode)
+    if code == 0 and K_ % 4 or code == 1 and K_ % 8:
+        K_ = (K_ // 8) * 8
+    dy, w = q(rnd(M, K_, seed=1), code), q(rnd(K_, N, seed=2, scale=0.05), code)
+    ref = dy @ w
+    ldb = ((N + 7) // 8) * 8
+    wp = torch.zeros(K_, ldb); wp[:, :N] = w
+    out = torch.empty(M, N, device='cuda')
+    K.gemm(dev(dy, code), dev(wp, code), M, N, K_, K_, ldb, code, b_mode=K.OP_K, out_f32=out, ldo_f32=N)
+    check(out, ref, code, 'gemm NN')
+
+
+@pytest.mark.parametrize('code', DTYPES)
+@pytest.mark.parametrize('rows,M,N,splitk', [(197, 768, 768, 1), (1030, 256, 3072, 4), (8200, 128, 128, 16), (333, 21, 256, 2)])
+def test_gemm_tn_atomic(K, code, rows, M, N, splitk):
+    # dW[M,N] += dy[rows,M]^T x[rows,N]
+    ldm = ((M + 7) // 8) * 8
+    dy = torch.zeros(rows, ldm); dy[:, :M] = q(rnd(rows, M, seed=1), code)
+    x = q(rnd(rows, N, seed=2), code)
+    base = rnd(M, N, seed=3)
+    ref = base + dy[:, :M].t() @ x
+    out = dev(base.clone())
+    K.gemm(dev(dy, code), dev(x, code), M, N, rows, ldm, N, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=out, ldo_f32=N,
+           atomic=True, splitk=splitk)
+    check(out, ref, code, 'gemm TN split-K atomic', tol=max(TOL[code], 2e-4 if code == 0 else 3e-2))
+
+
+@pytest.mark.parametrize('code', DTYPES)
+def test_patch_embed(K, code):
+    B, H, W = 2, 64, 96
+    img = rnd(B, 3, H, W, seed=1)
+    w, b = q(rnd(768, 3, 16, 16, seed=2, scale=0.05), code), rnd(768, seed=3)
+    cls, pos = rnd(1, 1, 768, seed=4), rnd(1, 1 + (H // 16) * (W // 16), 768, seed=5)
+    patches, hw = O.patch_embed(q(img, code), w, b)
+    ref = O.assemble_tokens(patches, cls, pos)
+    tpi = hw[0] * hw[1]
+    cols = torch.empty(B * tpi, 768, device='cuda', dtype=tdt(code))
+    K.im2col_patch16(dev(img), cols, code)
+    tokens = torch.zeros(B, tpi + 1, 768, device='cuda')
+    K.gemm(cols, dev(w.reshape(768, 768), code), B * tpi, 768, 768, 768, 768, code, bias=dev(b), out_f32=tokens,
+           ldo_f32=768, rowmap_tpi=tpi, pos=dev(pos.reshape(-1, 768)))
+    K.cls_pos(dev(cls.reshape(-1)), dev(pos.reshape(-1, 768)), tokens)
+    check(tokens, ref, code, 'patch embed + token assembly')
+    # backward of the assembly
+    dtok = rnd(B, tpi + 1, 768, seed=6)
+    dpos, dcls = torch.zeros(tpi + 1, 768, device='cuda'), torch.zeros(768, device='cuda')
+    K.tokens_bwd(dev(dtok), dpos, dcls)
+    check(dpos, dtok.sum(0), 0, 'dpos')
+    check(dcls, dtok[:, 0].sum(0), 0, 'dcls')
+
+
+@pytest.mark.parametrize('code', DTYPES)
+def test_colsum_cast(K, code):
+    M, N = 1030, 300
+    x = q(rnd(M, 304, seed=1), code)
+    out = torch.zeros(N, device='cuda')
+    K.colsum(dev(x, code), 304, M, N, out, code)
+    check(out, x[:, :N].sum(0), code, 'colsum', tol=1e-4 if code == 0 else 1e-2)
+    src = rnd(100003, seed=2)
+    dst = torch.empty(100003, device='cuda', dtype=tdt(code))
+    K.cast(dev(src), dst, code)
+    assert torch.equal(dst.cpu(), src.to(tdt(code)))
+    back = torch.empty(100003, device='cuda')
+    K.cast_back(dst, back, code)
+    assert torch.equal(back.cpu(), src.to(tdt(code)).float())
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize('code', DTYPES)
+@pytest.mark.parametrize('skip', [0, 1])
+def test_layernorm(K, code, skip):
+    B, ntok, C = 3, 197, 768
+    x = rnd(B, ntok, C, seed=1, scale=2.0) + 0.5
+    x[0, 5] = 1.25                                    # constant row
+    gamma, beta = rnd(C, seed=2) * 0.1 + 1.0, rnd(C, seed=3) * 0.1
+    xin = x[:, skip:].reshape(-1, C).clone().requires_grad_(True)
+    g, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = O.layernorm(xin, g, bt, 1e-6)
+    rows = xin.shape[0]
+    dy = q(rnd(rows, C, seed=4), code)
+    y.backward(dy)
+    yk = torch.empty(rows, C, device='cuda', dtype=tdt(code))
+    mean, rstd = torch.empty(rows, device='cuda'), torch.empty(rows, device='cuda')
+    xd = dev(x)
+    K.layernorm_fwd(xd, dev(gamma), dev(beta), yk, mean, rstd, rows, C, code, 1e-6, rows_per_img=ntok - skip, skip=skip)
+    check(yk, y, code, 'layernorm fwd', tol=1e-4 if code == 0 else 1e-2)
+    check(mean, xin.detach().mean(-1), 0, 'ln mean')
+    dres = rnd(B, ntok, C, seed=5)
+    dx = torch.zeros(B, ntok, C, device='cuda')
+    dx_t = torch.zeros(B, ntok, C, device='cuda', dtype=tdt(code))
+    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    K.layernorm_bwd(dev(dy, code), xd, mean, rstd, dev(gamma), dev(dres), dx, dx_t, dg, db, rows, C, code,
+                    rows_per_img=ntok - skip, skip=skip)
+    ref_dx = (xin.grad.reshape(B, ntok - skip, C) + dres[:, skip:])
+    check(dx[:, skip:], ref_dx, code, 'layernorm dx (+resid)', tol=1e-4 if code == 0 else 1e-2)
+    check(dx_t[:, skip:], ref_dx, code, 'layernorm dx T copy', tol=1e-4 if code == 0 else 1e-2)
+    check(dg, g.grad, code, 'layernorm dgamma', tol=2e-4 if code == 0 else 1e-2)
+    check(db, bt.grad, code, 'layernorm dbeta', tol=2e-4 if code == 0 else 1e-2)
+    if skip:
+        assert float(dx[:, 0].abs().max()) == 0.0, 'cls rows must stay untouched'
+        # accumulate mode
+        base = rnd(B, ntok, C, seed=6)
+        dx2 = dev(base.clone())
+        K.layernorm_bwd(dev(dy, code), xd, mean, rstd, dev(gamma), None, dx2, None, dg, db, rows, C, code,
+                        rows_per_img=ntok - skip, skip=skip, accumulate=True)
+        check(dx2[:, skip:], base[:, skip:] + xin.grad.reshape(B, ntok - skip, C), code, 'layernorm accumulate',
+              tol=1e-4 if code == 0 else 1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize('code', DTYPES)
+@pytest.mark.parametrize('B,N,H,bias', [(2, 197, 12, 0), (1, 130, 3, 1), (2, 65, 2, 2), (1, 1025, 2, 0)])
+def test_attention(K, code, B, N, H, bias):
+    C = H * 64
+    qkv = q(rnd(B, N, 3 * C, seed=1), code)
+    dctx = q(rnd(B, N, C, seed=2), code)
+    bias_full = bias_u = flag = None
+    w = 0.0
+    if bias:
+        u = torch.rand(B, N - 1, generator=torch.Generator().manual_seed(3))
+        w = 5.0
+        bias_full = O.pasa_bias(u, w, adaptive=(bias == 2))
+        bias_u, flag = O.pasa_rank1(u, adaptive=(bias == 2))
+    qr = qkv.clone().requires_grad_(True)
+    ctx_ref, lse_ref = O.attention_core(qr, H, bias_full)
+    ctx_ref.backward(dctx)
+    ctx = torch.empty(B, N, C, device='cuda', dtype=tdt(code))
+    lse = torch.empty(B, H, N, device='cuda')
+    qd = dev(qkv, code)
+    bu = dev(bias_u) if bias else None
+    fl = dev(flag) if bias == 2 else None
+    K.attention_fwd(qd, ctx, lse, B, N, H, code, bias_u=bu, row_flag=fl, bias_w=w)
+    check(ctx, ctx_ref, code, 'attention ctx', tol=1e-4 if code == 0 else 2e-2)
+    check(lse, lse_ref, code, 'attention lse', tol=1e-4 if code == 0 else 1e-2)
+    delta = torch.empty(B, H, N, device='cuda')
+    dqkv = torch.full((B, N, 3 * C), float('nan'), device='cuda', dtype=tdt(code))
+    # backward consumes the kernel's own forward outputs (as the training step does)
+    K.attention_bwd(qd, ctx, dev(dctx, code), lse, delta, dqkv, B, N, H, code, bias_u=bu, row_flag=fl, bias_w=w)
+    for i, nm in enumerate(('dq', 'dk', 'dv')):
+        check(dqkv[..., i * C:(i + 1) * C], qr.grad[..., i * C:(i + 1) * C], code, f'attention {nm}',
+              tol=2e-4 if code == 0 else 4e-2)
+
+
+# ------------------------------------------------------------------------------------------------ conv3x3
+def to_nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize('code', DTYPES)
+@pytest.mark.parametrize('B,Cin,Cout,H,W', [(2, 768, 256, 8, 8), (2, 256, 256, 16, 12), (1, 256, 256, 40, 40)])
+def test_conv3x3(K, code, B, Cin, Cout, H, W):
+    x = q(rnd(B, Cin, H, W, seed=1), code)
+    w = q(rnd(Cout, Cin, 3, 3, seed=2, scale=0.03), code)
+    dy = q(rnd(B, Cout, H, W, seed=3), code)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = O.conv3x3(xr, wr)
+    y.backward(dy)
+    M = B * H * W
+    xh = dev(to_nhwc(x), code)                       # [B,H,W,Cin]
+    wp = dev(w.permute(0, 2, 3, 1), code)            # physical [Cout][ky][kx][Cin]
+    out = torch.empty(M, Cout, device='cuda', dtype=tdt(code))
+    K.gemm(xh, wp, M, Cout, 9 * Cin, Cin, 9 * Cin, code, a_mode=K.OP_ROW_CONV, out_t=out, ldo_t=Cout,
+           conv=(B, H, W, Cin, 1))
+    check(out.reshape(B, H, W, Cout), to_nhwc(y), code, 'conv3x3 fwd')
+    dyh = dev(to_nhwc(dy), code)
+    dx = torch.empty(M, Cin, device='cuda', dtype=tdt(code))
+    K.gemm(dyh, wp, M, Cin, 9 * Cout, Cout, 9 * Cin, code, a_mode=K.OP_ROW_CONV, b_mode=K.OP_K_TAPSPLIT, out_t=dx,
+           ldo_t=Cin, conv=(B, H, W, Cout, -1))
+    check(dx.reshape(B, H, W, Cin), to_nhwc(xr.grad), code, 'conv3x3 dgrad')
+    dw = torch.zeros(Cout, 9 * Cin, device='cuda')
+    K.gemm(dyh, xh, Cout, 9 * Cin, M, Cout, Cin, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV, out_f32=dw, ldo_f32=9 * Cin,
+           atomic=True, splitk=3, conv=(B, H, W, Cin, 1))
+    check(dw.reshape(Cout, 3, 3, Cin), wr.grad.permute(0, 2, 3, 1), code, 'conv3x3 wgrad', tol=2e-4 if code == 0 else 3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ BN + ReLU + upsample
+@pytest.mark.parametrize('code', DTYPES)
+@pytest.mark.parametrize('s', [1, 2, 4])
+def test_bn_relu_up(K, code, s):
+    B, C, h, w = 2, 256, 6, 10
+    x = q(rnd(B, C, h, w, seed=1) * 1.5 + 0.3, code)
+    gamma, beta = rnd(C, seed=2) * 0.2 + 1.0, rnd(C, seed=3) * 0.2
+    rm, rv = rnd(C, seed=4) * 0.1, torch.rand(C, generator=torch.Generator().manual_seed(5)) + 0.5
+    xr, g_, b_ = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y = O.batchnorm_train(xr, g_, b_, rm_ref, rv_ref)
+    y = torch.relu(y)
+    y = O.upsample(y, s) if s > 1 else y
+    dy = q(rnd(*y.shape, seed=6), code)
+    y.backward(dy)
+
+    rows = B * h * w
+    xh = dev(to_nhwc(x), code)
+    sums = torch.zeros(2 * C, device='cuda')
+    K.bn_stats(xh, rows, C, sums, code)
+    rmd, rvd = dev(rm.clone()), dev(rv.clone())
+    scale, shift, mean, rstd = (torch.empty(C, device='cuda') for _ in range(4))
+    K.bn_finalize(sums, rows, dev(gamma), dev(beta), rmd, rvd, 0.1, 1e-5, True, scale, shift, mean, rstd, C)
+    check(rmd, rm_ref, 0, 'running_mean', tol=1e-5)
+    check(rvd, rv_ref, 0, 'running_var', tol=1e-5)
+    yk = torch.empty(B, h * s, w * s, C, device='cuda', dtype=tdt(code))
+    K.bn_relu_up_fwd(xh, scale, shift, yk, B, h, w, C, s, code)
+    check(yk, to_nhwc(y), code, 'bn+relu+up fwd', tol=1e-4 if code == 0 else 1.5e-2)
+    g = torch.empty(B, h, w, C, device='cuda', dtype=tdt(code))
+    bsums = torch.zeros(2 * C, device='cuda')
+    K.bn_relu_up_bwd(dev(to_nhwc(dy), code), xh, scale, shift, mean, rstd, g, bsums, B, h, w, C, s, code)
+    dx = torch.empty(B, h, w, C, device='cuda', dtype=tdt(code))
+    K.bn_bwd_apply(g, xh, mean, rstd, dev(gamma), bsums, rows, dx, rows, C, code)
+    dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    K.bn_param_grads(bsums, dgam, dbet, C)
+    check(dx, to_nhwc(xr.grad), code, 'bn+relu+up dx', tol=2e-4 if code == 0 else 3e-2)
+    check(dgam, g_.grad, code, 'bn dgamma', tol=2e-4 if code == 0 else 3e-2)
+    check(dbet, b_.grad, code, 'bn dbeta', tol=2e-4 if code == 0 else 3e-2)
+    # eval mode (teacher): running stats, no update
+    K.bn_finalize(None, 0, dev(gamma), dev(beta), rmd, rvd, 0.1, 1e-5, False, scale, shift, mean, rstd, C)
+    K.bn_relu_up_fwd(xh, scale, shift, yk, B, h, w, C, s, code)
+    ye = torch.relu(O.batchnorm_eval(x, gamma, beta, rm_ref, rv_ref))
+    ye = O.upsample(ye, s) if s > 1 else ye
+    check(yk, to_nhwc(ye), code, 'bn eval + relu + up', tol=1e-4 if code == 0 else 1.5e-2)
+    check(rmd, rm_ref, 0, 'running_mean unchanged in eval', tol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def make_labels(B, H, W, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    lab = torch.randint(0, C, (B, H, W), generator=g)
+    lab[:, :3, :] = 255
+    lab[:, :, -2:] = 255
+    return lab
+
+
+@pytest.mark.parametrize('s', [1, 2, 4])
+@pytest.mark.parametrize('C', [21, 19])
+def test_upsample_ce(K, s, C):
+    B, h, w, ldc = 2, 12, 9, 32
+    lo = rnd(B, C, h, w, seed=1, scale=3.0)
+    lab = make_labels(B, h * s, w * s, C, seed=2)
+    lor = lo.clone().requires_grad_(True)
+    z = O.upsample(lor, s) if s > 1 else lor
+    loss = O.ce_mean_all(z, lab, 255, loss_weight=0.4)
+    loss.backward()
+    lod = torch.zeros(B, h, w, ldc); lod[..., :C] = to_nhwc(lo)
+    lod = dev(lod)
+    labd = dev(lab.to(torch.uint8))
+    ls = torch.zeros(1, device='cuda')
+    K.upce_fwd(lod, labd, ls, B, h, w, C, ldc, s)
+    numel = B * h * s * w * s
+    check(ls * (0.4 / numel), loss.reshape(1), 0, 'upsample+CE loss', tol=2e-5)
+    dlo = torch.full((B, h, w, ldc), 7.0, device='cuda')
+    dlo_t = torch.full((B, h, w, ldc), 7.0, device='cuda', dtype=torch.bfloat16)
+    K.upce_bwd(lod, labd, 0.4 / numel, dlo, dlo_t, B, h, w, C, ldc, s, 1)
+    check(dlo[..., :C], to_nhwc(lor.grad), 0, 'upsample+CE dlogits', tol=1e-4)
+    assert float(dlo[..., C:].abs().max()) == 0.0, 'padding columns must be zero'
+    check(dlo_t[..., :C], to_nhwc(lor.grad), 1, 'upsample+CE dlogits bf16 copy', tol=1e-2)
+    # all-ignored image -> loss 0, grad 0
+    lab0 = torch.full((B, h * s, w * s), 255, dtype=torch.uint8)
+    ls.zero_()
+    K.upce_fwd(lod, dev(lab0), ls, B, h, w, C, ldc, s)
+    assert float(ls) == 0.0
+    K.upce_bwd(lod, dev(lab0), 1.0, dlo, None, B, h, w, C, ldc, s, 0)
+    assert float(dlo.abs().max()) == 0.0
+    # full-resolution NCHW logits for the API
+    full = torch.empty(B, C, h * s, w * s, device='cuda')
+    K.up_logits_nchw(lod, full, B, h, w, C, ldc, s)
+    check(full, z.detach(), 0, 'upsampled logits NCHW', tol=1e-5)
+
+
+@pytest.mark.parametrize('s', [1, 2])
+def test_pseudo_label(K, s):
+    B, C, h, w, ldc = 2, 21, 16, 16, 32
+    lo = rnd(B, C, h, w, seed=1, scale=4.0)                  # logits ~ N(0, 4^2)
+    if s == 1:
+        lo[0, :, 0, 0] = 0.0                                 # all tie -> first index, p = 1/21
+        lo[0, :, 0, 1] = -50.0; lo[0, 7, 0, 1] = 50.0        # p = 1 exactly
+        lo[0, :, 0, 2] = 0.0; lo[0, 3, 0, 2] = 5.0; lo[0, 9, 0, 2] = 5.0   # tie between 3 and 9 -> 3
+    z = O.upsample(lo, s) if s > 1 else lo
+    lab_ref, conf_ref = O.pseudo_label(z, 0.95)
+    lod = torch.zeros(B, h, w, ldc); lod[..., :C] = to_nhwc(lo)
+    lab = torch.empty(B, h * s, w * s, device='cuda', dtype=torch.uint8)
+    conf = torch.empty(B, h * s, w * s, device='cuda', dtype=torch.uint8)
+    cnt = torch.zeros(1, device='cuda', dtype=torch.int64)
+    K.up_pseudo_label(dev(lod), lab, conf, cnt, 0.95, B, h, w, C, ldc, s)
+    if s == 1:
+        assert torch.equal(lab.cpu().long(), lab_ref), 'pseudo labels must be bit-exact on identical logits'
+        assert torch.equal(conf.cpu().long(), conf_ref.long())
+        assert int(cnt) == int(conf_ref.sum())
+    else:
+        # interpolation rounding may differ in the last ulp: allow flips only where the decision is marginal
+        p = torch.softmax(z, 1)
+        top2 = p.topk(2, dim=1)[0]
+        marginal = ((top2[:, 0] - top2[:, 1]) < 1e-5) | ((top2[:, 0] - 0.95).abs() < 1e-5)
+        bad = (lab.cpu().long() != lab_ref) & ~marginal
+        assert int(bad.sum()) == 0
+        assert abs(int(cnt) - int(conf_ref.sum())) <= int(marginal.sum())
+    assert 0.05 < float(conf_ref.float().mean()) < 0.95, 'fixture must exercise both outcomes'
+
+
+def test_ce_known_answers(K):
+    """reference tests/test_models/test_losses/test_ce_loss.py:25-39,199-254 known answers"""
+    def run(logits, labels, cw=None, ignore=-100):
+        N, C = logits.shape[0], logits.shape[1]
+        spatial = int(np.prod(logits.shape[2:])) if logits.dim() > 2 else 1
+        out = torch.empty(N * spatial, device='cuda')
+        K.ce_fwd(dev(logits), dev(labels), dev(cw) if cw is not None else None, out, N, C, spatial, ignore)
+        return out.cpu()
+    le = run(torch.tensor([[100., -100.]]), torch.tensor([1]))
+    assert abs(float(le.mean()) - 200.0) < 1e-4
+    le = run(torch.tensor([[100., -100.]]), torch.tensor([1]), cw=torch.tensor([0.8, 0.2]))
+    assert abs(float(le.mean()) - 40.0) < 1e-4
+    pred = torch.full((2, 21, 8, 8), 0.5)
+    lab = torch.ones(2, 8, 8, dtype=torch.long); lab[:, 0, 0] = 255
+    le = run(pred, lab, ignore=255)
+    assert abs(float(le.sum() / le.numel()) - math.log(21) * 126 / 128) < 1e-5      # avg_non_ignore=False
+    assert abs(float(le.sum() / (lab != 255).sum()) - math.log(21)) < 1e-5          # avg_non_ignore=True
+    # random + backward vs oracle
+    lg = rnd(3, 21, 7, 5, seed=1, scale=3.0)
+    lb = make_labels(3, 7, 5, 21, seed=2)
+    cw = torch.rand(21, generator=torch.Generator().manual_seed(3)) + 0.5
+    lr_ = lg.clone().requires_grad_(True)
+    ref = O.ce_none(lr_, lb, 255, cw)
+    dl = rnd(3, 7, 5, seed=4)
+    ref.backward(dl)
+    le = run(lg, lb, cw, 255)
+    check(le.reshape(3, 7, 5), ref, 0, 'ce_fwd', tol=1e-5)
+    dlg = torch.empty(3, 21, 7, 5, device='cuda')
+    K.ce_bwd(dev(lg), dev(lb), dev(cw), dev(dl), dlg, 3, 21, 35, 255)
+    check(dlg, lr_.grad, 0, 'ce_bwd', tol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ EMA / SGD
+@pytest.mark.parametrize('code', DTYPES)
+def test_ema_sgd(K, code):
+    n = 769 + 2304 * 768 + 1
+    t, s = rnd(n, seed=1), rnd(n, seed=2)
+    td, sd = dev(t.clone()), dev(s)
+    tt = torch.empty(n, device='cuda', dtype=tdt(code))
+    ref = t.clone()
+    for _ in range(3):
+        O.ema_update(ref, s, 0.999)
+        K.ema(td, sd, tt, n, 0.999, code)
+    check(td, ref, 0, 'ema', tol=2e-7)
+    assert torch.equal(tt.cpu(), td.cpu().to(tdt(code)))
+    # SGD momentum vs torch.optim.SGD, two lr groups emulated by two calls
+    p = torch.nn.Parameter(rnd(n, seed=3))
+    opt = torch.optim.SGD([p], lr=0.01, momentum=0.9, weight_decay=0.0)
+    pd, buf = dev(p.detach().clone()), torch.zeros(n, device='cuda')
+    for it in range(3):
+        g = rnd(n, seed=10 + it)
+        p.grad = g.clone()
+        lr = O.poly_lr(0.01, it, 80001)
+        opt.param_groups[0]['lr'] = lr
+        opt.step()
+        K.sgd_momentum(pd, dev(g), buf, None, n, lr, 0.9, 1.0, it == 0, code)
+    check(pd, p.detach(), 0, 'sgd momentum', tol=2e-7)
