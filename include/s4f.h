@@ -75,9 +75,9 @@ typedef struct s4f_gemm_desc {
   int64_t ld_aux;
   int32_t act;
   int32_t atomic;           /* 1: atomicAdd into out_f32 (which the caller pre-zeroed / accumulates into) */
-  /* token row map (patch embed): out row = m + m / rowmap_tpi + 1 ; adds pos[(m % tpi) + 1][n] */
-  int32_t rowmap_tpi;       /* 0 = identity */
-  const float* pos;         /* fp32 [(tpi+1), N] or NULL */
+  /* position-embedding add (patch embed): v += pos[(m % pos_period), n] */
+  int32_t pos_period;
+  const float* pos;         /* fp32 [pos_period, N] or NULL */
 } s4f_gemm_desc;
 
 int s4f_gemm(const s4f_gemm_desc* d, s4f_stream stream);
@@ -88,30 +88,35 @@ int s4f_cast(const float* src, void* dst, int64_t n, int dtype, s4f_stream strea
 /* s4f_cast_back: T -> fp32 */
 int s4f_cast_back(const void* src, float* dst, int64_t n, int dtype, s4f_stream stream);
 
-/* PatchEmbed im2col (embed.py:183-204): img fp32 [B,3,H,W] -> cols T [B*(H/16)*(W/16), 768], feature order
- * (c, ky, kx), token order row-major over the patch grid. H, W multiples of 16. */
-int s4f_im2col_patch16(const float* img, void* cols, int B, int H, int W, int dtype, s4f_stream stream);
+/* PatchEmbed im2col (embed.py:183-204): img fp32 [B,3,H,W] -> cols T, feature order (c, ky, kx), token order
+ * row-major over the patch grid. H, W multiples of 16.  pad_cls = 0: cols [B*T, 768] (T = (H/16)*(W/16));
+ * pad_cls = 1: cols [B*(T+1), 768] with row 0 of every image left untouched (the caller zeroes it once): the
+ * rows then line up with the token tensor [B, T+1, 768] (cls first, vit.py:486-487). */
+int s4f_im2col_patch16(const float* img, void* cols, int B, int H, int W, int pad_cls, int dtype, s4f_stream stream);
 
 /* tokens[b, 0, :] = cls + pos[0]  (vit.py:486-487,445). tokens fp32 [B, ntok, C]. */
 int s4f_cls_pos(const float* cls, const float* pos, float* tokens, int B, int ntok, int C, s4f_stream stream);
 /* backward of token assembly: dpos[t,:] += sum_b dtok[b,t,:]; dcls += sum_b dtok[b,0,:] (atomic into fp32) */
 int s4f_tokens_bwd(const float* dtok, float* dpos, float* dcls, int B, int ntok, int C, s4f_stream stream);
 
-/* column sums (bias gradients): out[n] += sum_m X[m, n], X is T [M, ld]. */
-int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int dtype, s4f_stream stream);
+/* column sums (bias gradients): out[n] += sum_m X[m, n], X is T [M, ld]; rows with m % skip_period == 0 are
+ * left out when skip_period > 0 (cls rows of a token tensor). */
+int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int skip_period, int dtype, s4f_stream stream);
 
-/* LayerNorm (vit.py:67-69,82-84; setr_up_head.py:49,103).  x fp32 rows; row r of the output reads input row
- * r + r / rows_per_img * skip + skip (skip = 1 drops the cls token of each image: the head's token->NCHW
- * reshape, vit.py:555-562, is folded into this index map; skip = 0 is the identity).
+/* LayerNorm (vit.py:67-69,82-84; setr_up_head.py:49,103).  x fp32; output row r = (image b = r / rows_per_img,
+ * token t = r % rows_per_img) reads x + b * in_batch_stride + t * C  (in_batch_stride in elements; with
+ * x pointing at token 1 and in_batch_stride = (T+1)*C this drops the cls token of each image: the head's
+ * token->NCHW reshape, vit.py:555-562, is folded into this index map).  rows_per_img = rows, stride 0: plain.
  * y T [rows, C]; mean, rstd fp32 [rows]. C % 256 == 0, C <= 1024. */
 int s4f_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                      int rows, int C, int rows_per_img, int skip, float eps, int dtype, s4f_stream stream);
-/* dx[in_row] (=|+=) LN backward of dy (T) ; dgamma/dbeta accumulated atomically (fp32).
- * dresid: optional fp32 gradient of the residual branch added to the result (same row map as x).
- * dx fp32 output, dx_t optional T copy.  accumulate != 0: dx += (instead of =), dresid must then be NULL. */
+                      int rows, int C, int rows_per_img, int64_t in_batch_stride, float eps, int dtype,
+                      s4f_stream stream);
+/* dx (=|+=) LN backward of dy (T) ; dgamma/dbeta accumulated atomically (fp32).  dx, dx_t and dresid use the
+ * same (in_batch_stride) row map as x.  dresid: optional fp32 gradient of the residual branch added to the
+ * result.  dx fp32 output, dx_t optional T copy.  accumulate != 0: dx += (instead of =), dresid must be NULL. */
 int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* dresid, float* dx, void* dx_t, float* dgamma, float* dbeta, int rows, int C,
-                      int rows_per_img, int skip, int accumulate, int dtype, s4f_stream stream);
+                      int rows_per_img, int64_t in_batch_stride, int accumulate, int dtype, s4f_stream stream);
 
 /* out = a + b (fp32), optional T copy of the sum */
 int s4f_add_f32(const float* a, const float* b, float* out, void* out_t, int64_t n, int dtype, s4f_stream stream);
@@ -162,8 +167,10 @@ int s4f_bn_param_grads(const float* sums_local, float* dgamma, float* dbeta, int
  * labels: uint8 [B, h*s, w*s] (255 = ignore). Two launches: fwd (loss), bwd (dlo, recomputes softmax). */
 int s4f_upce_fwd(const float* logits_lo, const uint8_t* labels, float* loss_sum, int B, int h, int w, int C, int ldc,
                  int s, int ignore_index, s4f_stream stream);
-int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, float gscale, float* dlo, void* dlo_t, int B, int h,
-                 int w, int C, int ldc, int s, int ignore_index, int dtype, s4f_stream stream);
+/* gscale_dev: optional device fp32 scalar multiplied into gscale (the upstream d loss, read without a host sync) */
+int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, float gscale, const float* gscale_dev, float* dlo,
+                 void* dlo_t, int B, int h, int w, int C, int ldc, int s, int ignore_index, int dtype,
+                 s4f_stream stream);
 /* Teacher post-processing (encoder_decoder.py:888-901,541-542): label = argmax_c z (first index on ties),
  * conf = 1/sum exp(z - zmax) > th; label_out = conf ? label : 255; conf_count += number of confident pixels.
  * Also emits conf mask bytes (0/1) when conf_out != NULL. */

@@ -37,7 +37,7 @@ class GemmDesc(Structure):
         ('out_pre', c_void_p), ('ldo_pre', c_int64),
         ('aux', c_void_p), ('ld_aux', c_int64),
         ('act', c_int32), ('atomic', c_int32),
-        ('rowmap_tpi', c_int32), ('pos', c_void_p),
+        ('pos_period', c_int32), ('pos', c_void_p),
     ]
 
 
@@ -45,13 +45,13 @@ _SIGS = {
     's4f_gemm': [POINTER(GemmDesc), c_void_p],
     's4f_cast': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     's4f_cast_back': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
-    's4f_im2col_patch16': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_im2col_patch16': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     's4f_cls_pos': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     's4f_tokens_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    's4f_colsum': [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p],
-    's4f_layernorm_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+    's4f_colsum': [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
+    's4f_layernorm_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64,
                           c_float, c_int, c_void_p],
-    's4f_layernorm_bwd': [c_void_p] * 10 + [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_layernorm_bwd': [c_void_p] * 10 + [c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p],
     's4f_add_f32': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     's4f_attention_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
                           c_void_p],
@@ -64,8 +64,8 @@ _SIGS = {
     's4f_bn_bwd_apply': [c_void_p] * 6 + [c_double, c_void_p, c_int64, c_int, c_int, c_void_p],
     's4f_bn_param_grads': [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     's4f_upce_fwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    's4f_upce_bwd': [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                     c_int, c_int, c_void_p],
+    's4f_upce_bwd': [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                     c_int, c_int, c_int, c_void_p],
     's4f_up_pseudo_label': [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int,
                             c_int, c_void_p],
     's4f_up_logits_nchw': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

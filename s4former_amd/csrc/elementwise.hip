@@ -46,7 +46,7 @@ __global__ void cast_back_kernel(const T* __restrict__ src, float* __restrict__ 
 // ---------------------------------------------------------------- patch im2col (16x16, stride 16)
 // one thread per 4 consecutive kx of one (token, c, ky): reads 16 B of the image row, writes 4 features.
 template <typename T>
-__global__ void im2col16_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H, int W) {
+__global__ void im2col16_kernel(const float* __restrict__ img, T* __restrict__ cols, int B, int H, int W, int pad_cls) {
   const int gh = H / 16, gw = W / 16;
   const long total = (long)B * gh * gw * 192;   // 768 / 4 groups per token
   const long stride = (long)gridDim.x * blockDim.x;
@@ -61,7 +61,7 @@ __global__ void im2col16_kernel(const float* __restrict__ img, T* __restrict__ c
     const int py = t2 % gh;
     const int b = t2 / gh;
     const f32x4 v = *reinterpret_cast<const f32x4*>(img + (((long)b * 3 + c) * H + (py * 16 + ky)) * W + px * 16 + kx0);
-    T* o = cols + tok * 768 + f4 * 4;
+    T* o = cols + (pad_cls ? tok + b + 1 : tok) * 768 + f4 * 4;
     if constexpr (sizeof(T) == 2) {
       bf16x4 ov;
       ov[0] = (bf16_t)v[0]; ov[1] = (bf16_t)v[1]; ov[2] = (bf16_t)v[2]; ov[3] = (bf16_t)v[3];
@@ -96,7 +96,8 @@ __global__ void tokens_bwd_kernel(const float* __restrict__ dtok, float* __restr
 // ---------------------------------------------------------------- column sums
 // block = 256 threads = 64 columns x 4 row lanes; grid.x = column blocks of 64, grid.y = row slabs
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ X, long ld, int M, int N, float* __restrict__ out, int rows_per_block) {
+__global__ void colsum_kernel(const T* __restrict__ X, long ld, int M, int N, float* __restrict__ out, int rows_per_block,
+                              int skip_period) {
   __shared__ float red[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + cx;
@@ -105,7 +106,10 @@ __global__ void colsum_kernel(const T* __restrict__ X, long ld, int M, int N, fl
   if (r1 > M) r1 = M;
   float s = 0.f;
   if (col < N)
-    for (int r = r0 + ry; r < r1; r += 4) s += to_f32<T>(X[(long)r * ld + col]);
+    for (int r = r0 + ry; r < r1; r += 4) {
+      if (skip_period > 0 && (r % skip_period) == 0) continue;
+      s += to_f32<T>(X[(long)r * ld + col]);
+    }
   red[ry][cx] = s;
   __syncthreads();
   if (ry == 0 && col < N) atomicAdd(out + col, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
@@ -113,15 +117,17 @@ __global__ void colsum_kernel(const T* __restrict__ X, long ld, int M, int N, fl
 
 // ---------------------------------------------------------------- LayerNorm
 // one wave per row; lane holds NV groups of 4 consecutive channels: channel = v*256 + lane*4 + e
-__device__ __forceinline__ long ln_in_row(int r, int rows_per_img, int skip) {
-  return skip ? (long)r + (long)(r / rows_per_img) * skip + skip : (long)r;
+// element offset of the input row that output row r reads
+__device__ __forceinline__ long ln_in_off(int r, int rows_per_img, long bstride, int C) {
+  const int b = r / rows_per_img;
+  return (long)b * bstride + (long)(r - b * rows_per_img) * C;
 }
 
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                     int rows_per_img, int skip, float eps) {
+                                                     int rows_per_img, long bstride, float eps) {
   constexpr int C = NV * 256;
   const int lane = threadIdx.x & 63;
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     bt[v] = *reinterpret_cast<const f32x4*>(beta + v * 256 + lane * 4);
   }
   for (int r = wave_global; r < rows; r += nwaves) {
-    const float* xr = x + ln_in_row(r, rows_per_img, skip) * C;
+    const float* xr = x + ln_in_off(r, rows_per_img, bstride, C);
     f32x4 xv[NV];
     float s = 0.f;
 #pragma unroll
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      const float* __restrict__ gamma, const float* __restrict__ dresid,
                                                      float* __restrict__ dx, T* __restrict__ dx_t,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                     int rows_per_img, int skip, int accumulate) {
+                                                     int rows_per_img, long bstride, int accumulate) {
   constexpr int C = NV * 256;
   __shared__ float red[2][4][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -202,8 +208,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     db[v] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (int r = wave_global; r < rows; r += nwaves) {
-    const long ir = ln_in_row(r, rows_per_img, skip);
-    const float* xr = x + ir * C;
+    const long io = ln_in_off(r, rows_per_img, bstride, C);
+    const float* xr = x + io;
     const T* dyr = dy + (long)r * C;
     const float mu = mean[r], rs = rstd[r];
     f32x4 xh[NV], dyv[NV];
@@ -229,15 +235,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = rs * (dyv[v][e] * gm[v][e] - s1 - xh[v][e] * s2);
-      float* dxr = dx + ir * C + v * 256 + lane * 4;
+      float* dxr = dx + io + v * 256 + lane * 4;
       if (dresid) {
-        const f32x4 dr = *reinterpret_cast<const f32x4*>(dresid + ir * C + v * 256 + lane * 4);
+        const f32x4 dr = *reinterpret_cast<const f32x4*>(dresid + io + v * 256 + lane * 4);
         o += dr;
       } else if (accumulate) {
         o += *reinterpret_cast<const f32x4*>(dxr);
       }
       *reinterpret_cast<f32x4*>(dxr) = o;
-      if (dx_t) store4<T>(dx_t + ir * C + v * 256 + lane * 4, o);
+      if (dx_t) store4<T>(dx_t + io + v * 256 + lane * 4, o);
     }
   }
   // block reduction of dgamma / dbeta, then one atomic per column per block
@@ -344,15 +350,15 @@ S4F_API int s4f_cast_back(const void* src, float* dst, int64_t n, int dtype, s4f
   return 0;
 }
 
-S4F_API int s4f_im2col_patch16(const float* img, void* cols, int B, int H, int W, int dtype, s4f_stream stream) {
+S4F_API int s4f_im2col_patch16(const float* img, void* cols, int B, int H, int W, int pad_cls, int dtype, s4f_stream stream) {
   DT_CHECK("s4f_im2col_patch16");
   S4F_CHECK(img && cols && B > 0, "s4f_im2col_patch16: bad args");
   S4F_CHECK(H % 16 == 0 && W % 16 == 0 && H > 0 && W > 0, "s4f_im2col_patch16: H, W must be multiples of 16 (got %d x %d)", H, W);
   S4F_CHECK(((uintptr_t)img % 16) == 0, "s4f_im2col_patch16: img must be 16-B aligned");
   const long total = (long)B * (H / 16) * (W / 16) * 192;
   const int grid = grid_for(total, 256);
-  if (dtype == S4F_BF16) hipLaunchKernelGGL(im2col16_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, B, H, W);
-  else hipLaunchKernelGGL(im2col16_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, H, W);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(im2col16_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (bf16_t*)cols, B, H, W, pad_cls);
+  else hipLaunchKernelGGL(im2col16_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, img, (float*)cols, B, H, W, pad_cls);
   S4F_LAUNCH_CHECK();
   return 0;
 }
@@ -371,13 +377,13 @@ S4F_API int s4f_tokens_bwd(const float* dtok, float* dpos, float* dcls, int B, i
   return 0;
 }
 
-S4F_API int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int dtype, s4f_stream stream) {
+S4F_API int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int skip_period, int dtype, s4f_stream stream) {
   DT_CHECK("s4f_colsum");
   S4F_CHECK(X && out && M > 0 && N > 0 && ld >= N, "s4f_colsum: bad args");
   const int rows_per_block = 128;
   dim3 grid(ceil_div(N, 64), ceil_div(M, rows_per_block));
-  if (dtype == S4F_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, (long)ld, M, N, out, rows_per_block);
-  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, (long)ld, M, N, out, rows_per_block);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, (long)ld, M, N, out, rows_per_block, skip_period);
+  else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, (long)ld, M, N, out, rows_per_block, skip_period);
   S4F_LAUNCH_CHECK();
   return 0;
 }
@@ -391,30 +397,33 @@ S4F_API int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int 
   }
 
 S4F_API int s4f_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                              int rows, int C, int rows_per_img, int skip, float eps, int dtype, s4f_stream stream) {
+                              int rows, int C, int rows_per_img, int64_t in_batch_stride, float eps, int dtype,
+                              s4f_stream stream) {
   DT_CHECK("s4f_layernorm_fwd");
   S4F_CHECK(x && gamma && beta && y && mean && rstd, "s4f_layernorm_fwd: null pointer");
   S4F_CHECK(rows > 0 && C % 256 == 0 && C >= 256 && C <= 1024, "s4f_layernorm_fwd: C=%d must be a multiple of 256, <= 1024", C);
-  S4F_CHECK(skip == 0 || rows_per_img > 0, "s4f_layernorm_fwd: rows_per_img needed with skip");
+  S4F_CHECK(rows_per_img > 0, "s4f_layernorm_fwd: rows_per_img must be > 0");
+  const long bstride = (long)in_batch_stride;
   const int grid = grid_for(rows, 4);
-  if (dtype == S4F_BF16) { LN_DISPATCH(ln_fwd_kernel, bf16_t, x, gamma, beta, (bf16_t*)y, mean, rstd, rows, rows_per_img, skip, eps) }
-  else { LN_DISPATCH(ln_fwd_kernel, float, x, gamma, beta, (float*)y, mean, rstd, rows, rows_per_img, skip, eps) }
+  if (dtype == S4F_BF16) { LN_DISPATCH(ln_fwd_kernel, bf16_t, x, gamma, beta, (bf16_t*)y, mean, rstd, rows, rows_per_img, bstride, eps) }
+  else { LN_DISPATCH(ln_fwd_kernel, float, x, gamma, beta, (float*)y, mean, rstd, rows, rows_per_img, bstride, eps) }
   S4F_LAUNCH_CHECK();
   return 0;
 }
 
 S4F_API int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                               const float* dresid, float* dx, void* dx_t, float* dgamma, float* dbeta, int rows, int C,
-                              int rows_per_img, int skip, int accumulate, int dtype, s4f_stream stream) {
+                              int rows_per_img, int64_t in_batch_stride, int accumulate, int dtype, s4f_stream stream) {
   DT_CHECK("s4f_layernorm_bwd");
   S4F_CHECK(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "s4f_layernorm_bwd: null pointer");
   S4F_CHECK(rows > 0 && C % 256 == 0 && C >= 256 && C <= 1024, "s4f_layernorm_bwd: C=%d must be a multiple of 256, <= 1024", C);
   S4F_CHECK(!(accumulate && dresid), "s4f_layernorm_bwd: accumulate and dresid are exclusive");
-  S4F_CHECK(skip == 0 || rows_per_img > 0, "s4f_layernorm_bwd: rows_per_img needed with skip");
+  S4F_CHECK(rows_per_img > 0, "s4f_layernorm_bwd: rows_per_img must be > 0");
+  const long bstride = (long)in_batch_stride;
   int grid = grid_for(rows, 16);   // 4 rows per wave: fewer atomics on dgamma/dbeta
   if (grid > 512) grid = 512;
-  if (dtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)dy, x, mean, rstd, gamma, dresid, dx, (bf16_t*)dx_t, dgamma, dbeta, rows, rows_per_img, skip, accumulate) }
-  else { LN_DISPATCH(ln_bwd_kernel, float, (const float*)dy, x, mean, rstd, gamma, dresid, dx, (float*)dx_t, dgamma, dbeta, rows, rows_per_img, skip, accumulate) }
+  if (dtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)dy, x, mean, rstd, gamma, dresid, dx, (bf16_t*)dx_t, dgamma, dbeta, rows, rows_per_img, bstride, accumulate) }
+  else { LN_DISPATCH(ln_bwd_kernel, float, (const float*)dy, x, mean, rstd, gamma, dresid, dx, (float*)dx_t, dgamma, dbeta, rows, rows_per_img, bstride, accumulate) }
   S4F_LAUNCH_CHECK();
   return 0;
 }

@@ -272,13 +272,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs args) {
         const int m = m0 + wm * 64 + i * 16 + 4 * g + r;
         if (m >= d.M) continue;
         float v = acc[i][j][r] * d.alpha + bias;
-        long orow = m;
-        if (d.rowmap_tpi > 0) {
-          const int img = m / d.rowmap_tpi;
-          const int t = m - img * d.rowmap_tpi;
-          orow = (long)m + img + 1;
-          if (d.pos) v += d.pos[(long)(t + 1) * d.N + n];
-        }
+        const long orow = m;
+        if (d.pos) v += d.pos[(long)(m % d.pos_period) * d.N + n];
         if (d.act == S4F_ACT_GELU) {
           if (out_pre) out_pre[orow * d.ldo_pre + n] = from_f32<T>(v);
           v = gelu_f(v);
@@ -340,7 +335,10 @@ S4F_API int s4f_gemm(const s4f_gemm_desc* dp, s4f_stream stream) {
             "s4f_gemm: splitk > 1 needs atomic fp32 output and no activation");
   S4F_CHECK(d.act != S4F_ACT_GELU_BWD || d.aux, "s4f_gemm: GELU_BWD needs aux");
   // contraction chunks must not straddle K (row modes: K % epc; k modes: any K)
-  if (d.a_mode == S4F_OP_ROW || d.b_mode == S4F_OP_ROW) S4F_CHECK(d.K % epc == 0, "s4f_gemm: K %% %d != 0", epc);
+  // both operands contraction-contiguous: chunks must not straddle K.  With a k-major operand the rows >= K of
+  // that operand are zero-filled, so the other operand may carry (finite) padding up to its 16-B chunk.
+  if (d.a_mode != S4F_OP_K && d.b_mode == S4F_OP_ROW) S4F_CHECK(d.K % epc == 0, "s4f_gemm: K %% %d != 0", epc);
+  S4F_CHECK(d.pos == nullptr || d.pos_period > 0, "s4f_gemm: pos needs pos_period");
   if (d.a_mode == S4F_OP_ROW_CONV) {
     S4F_CHECK(d.cC % bk == 0, "s4f_gemm: conv channels %d not a multiple of %d", d.cC, bk);
     S4F_CHECK(d.K == 9 * d.cC, "s4f_gemm: conv K must be 9*cC");

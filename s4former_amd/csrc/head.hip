@@ -347,10 +347,12 @@ __global__ __launch_bounds__(256) void upce_fwd_kernel(const float* __restrict__
 // thread per low-res pixel: gathers w * gscale * (softmax - onehot) from every output pixel that reads it
 template <typename T>
 __global__ __launch_bounds__(256) void upce_bwd_kernel(const float* __restrict__ lo, const uint8_t* __restrict__ labels,
-                                                       float gscale, float* __restrict__ dlo, T* __restrict__ dlo_t, int B,
+                                                       float gscale, const float* __restrict__ gscale_dev,
+                                                       float* __restrict__ dlo, T* __restrict__ dlo_t, int B,
                                                        int h, int w, int C, int ldc, int s, int ignore) {
   const int H = h * s, W = w * s;
   const long total = (long)B * h * w;
+  if (gscale_dev) gscale *= *gscale_dev;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
     const int j = p % w;
@@ -589,15 +591,16 @@ S4F_API int s4f_upce_fwd(const float* logits_lo, const uint8_t* labels, float* l
   return 0;
 }
 
-S4F_API int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, float gscale, float* dlo, void* dlo_t, int B, int h,
-                         int w, int C, int ldc, int s, int ignore_index, int dtype, s4f_stream stream) {
+S4F_API int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, float gscale, const float* gscale_dev, float* dlo,
+                         void* dlo_t, int B, int h, int w, int C, int ldc, int s, int ignore_index, int dtype,
+                         s4f_stream stream) {
   DT_CHECK("s4f_upce_bwd");
   S4F_CHECK(logits_lo && labels && dlo, "s4f_upce_bwd: null pointer");
   LOGIT_CHECK("s4f_upce_bwd");
   const long total = (long)B * h * w;
   const int grid = grid_for(total, 256);
-  if (dtype == S4F_BF16) hipLaunchKernelGGL(upce_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, gscale, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, s, ignore_index);
-  else hipLaunchKernelGGL(upce_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, gscale, dlo, (float*)dlo_t, B, h, w, C, ldc, s, ignore_index);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(upce_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, s, ignore_index);
+  else hipLaunchKernelGGL(upce_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, gscale, gscale_dev, dlo, (float*)dlo_t, B, h, w, C, ldc, s, ignore_index);
   S4F_LAUNCH_CHECK();
   return 0;
 }

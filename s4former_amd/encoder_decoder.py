@@ -1,0 +1,408 @@
+"""EncoderDecoder segmentor of S4Former (mean-teacher semi-supervised SETR) with the reference's registry name,
+constructor kwargs, method names, loss keys and state-dict prefixes
+(reference mmseg/models/segmentors/encoder_decoder.py:25-163,386-687,875-934,1044-1066 and base.py:155-274),
+driving the MI355X HIP kernels: student + teacher replicas live in flat arenas (params.ParamStore), the EMA
+update is one launch, the teacher's pseudo-labels come from one fused kernel.
+
+Scope: the supervised branch, the mean-teacher EMA, teacher pseudo-labels with confidence threshold,
+the pseudo-label CE (`compute_pseudo_loss`), and the PASA attention bias (rank-1, never materialised).
+CutMix / PatchShuffle / NCR / UniMatch / fdrop switches are "next" rows and raise.
+"""
+from collections import OrderedDict
+from numbers import Number
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import kernels as K
+from . import runtime
+from ._lib import S4FError
+from .base_module import BaseModule
+from .functional import LOGIT_LD
+from .params import ParamStore
+from .registry import SEGMENTORS, build_backbone, build_head, build_neck
+
+
+def add_prefix(inputs, prefix):
+    """mmseg/core/utils/misc.py:4-17"""
+    return {f'{prefix}.{name}': value for name, value in inputs.items()}
+
+
+def dict_split(dict1, key):
+    """models/utils/structual_utils.py:42-53: group every field by dict1[key] (tensors are re-stacked)"""
+    groups = {}
+    names = list(dict.fromkeys(dict1[key]))
+    for name in names:
+        flag = [v == name for v in dict1[key]]
+        sel = {}
+        for k, v in dict1.items():
+            if isinstance(v, torch.Tensor):
+                idx = [i for i, f in enumerate(flag) if f]
+                if idx == list(range(idx[0], idx[-1] + 1)):
+                    sel[k] = v[idx[0]:idx[-1] + 1]          # contiguous group: a view, no copy
+                else:
+                    sel[k] = v[torch.tensor(idx, device=v.device)]
+            else:
+                sel[k] = [vv for vv, f in zip(v, flag) if f]
+        groups[name] = sel
+    return groups
+
+
+def weighted_loss(loss, weight, ignore_keys=()):
+    """models/utils/structual_utils.py:132-154 (warmup = 0)"""
+    if not isinstance(weight, Number):
+        raise NotImplementedError()
+    for name in list(loss.keys()):
+        if 'loss' in name:
+            loss[name] = loss[name] * (0.0 if any(k in name for k in ignore_keys) else weight)
+    return loss
+
+
+class BaseSegmentor(BaseModule):
+    """reference mmseg/models/segmentors/base.py (training entry points only)."""
+
+    def __init__(self, init_cfg=None):
+        super().__init__(init_cfg)
+        self.fp16_enabled = False
+        self.log_vars_as_tensors = False    # True: no host sync in _parse_losses (values stay 0-dim tensors)
+
+    @property
+    def with_neck(self):
+        return hasattr(self, 'neck') and self.neck is not None
+
+    @property
+    def with_auxiliary_head(self):
+        return hasattr(self, 'auxiliary_head') and self.auxiliary_head is not None
+
+    @property
+    def with_decode_head(self):
+        return hasattr(self, 'decode_head') and self.decode_head is not None
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        raise S4FError('inference entry points are outside the training hot path (SURVEY §8f-2, Q8)')
+
+    def train_step(self, data_batch, optimizer, **kwargs):
+        """base.py:155-206 without the per-iteration debug dumps to the CWD (Q6)."""
+        data_batch = dict(data_batch)
+        data_batch['iter'] = kwargs['iter']
+        losses = self(**data_batch)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data_batch['img_metas']))
+
+    def _parse_losses(self, losses):
+        """base.py:230-274.  The reference's one all-reduce + .item() per scalar becomes one batched all-reduce
+        and one device->host copy."""
+        log_vars = OrderedDict()
+        for name, value in losses.items():
+            if isinstance(value, torch.Tensor):
+                log_vars[name] = value.mean()
+            elif isinstance(value, list):
+                log_vars[name] = sum(v.mean() for v in value)
+            else:
+                raise TypeError(f'{name} is not a tensor or list of tensors')
+        loss = sum(v for k, v in log_vars.items() if 'loss' in k)
+        distributed = dist.is_available() and dist.is_initialized()
+        if distributed:
+            n = torch.tensor(len(log_vars), device=loss.device)
+            dist.all_reduce(n)
+            assert int(n) == len(log_vars) * dist.get_world_size(), \
+                'loss log variables are different across GPUs!\n' + f'rank {dist.get_rank()} keys: ' + ','.join(log_vars)
+        log_vars['loss'] = loss
+        packed = torch.stack([v.detach().reshape(()).to(torch.float32) for v in log_vars.values()])
+        if distributed:
+            packed = packed / dist.get_world_size()
+            dist.all_reduce(packed)
+        if self.log_vars_as_tensors:
+            vals = list(packed.unbind(0))
+        else:
+            vals = packed.tolist()
+        for k, v in zip(list(log_vars.keys()), vals):
+            log_vars[k] = v
+        return loss, log_vars
+
+
+_UNSUPPORTED_TRUE = ('sup_ema', 'attn_frozen', 'sup_ClassMix', 'sup_cutmix', 'unsup_soft', 'use_CutMix', 'use_CutOut',
+                     'use_ClassMix', 'mix_with_labeled', 'patchwise', 'use_PatchShuffle', 'use_PatchShuffle_w_Classmix',
+                     'use_PatchShuffle_w_Cutmix', 'no_pos_embed', 'avg_pos_emd', 'duplicate_pos_emd', 'attn_mask_w_fdrop',
+                     'negative_class_ranking', 'use_fdrop', 'unimatch', 'use_cutmix_adaptive', 'ema_test')
+
+
+@SEGMENTORS.register_module()
+class EncoderDecoder(BaseSegmentor):
+    def __init__(self, backbone, decode_head, neck=None, auxiliary_head=None, projection_head=None, backbone_ema=None,
+                 decode_head_ema=None, neck_ema=None, auxiliary_head_ema=None, projection_head_ema=None,
+                 backbone_pretrain=None, pretrained=None, train_cfg=None, test_cfg=None, init_cfg=None,
+                 ema=False, sup_ema=False, ema_momentum=0.999, attn_frozen=False, attn_frozen_rate=0.0,
+                 momentum_backbone=None, momentum_head=None, momentum_head_dropout=0.0, momentum_head_exp=0.0,
+                 momentum_exp=0.0, ema_test=False, sup_ClassMix=False, sup_cutmix=False, unsup_weight=2.0,
+                 unsup_confidence=0.75, unsup_soft=False, unsup_temperature=1.0, iter_unsup_start=0, strong_aug_prob=0.5,
+                 cutout_area=2, use_CutMix=False, use_CutOut=False, use_ClassMix=False, mix_with_labeled=False,
+                 patchwise=False, use_PatchShuffle=False, PatchMix_N=8, patchmix_ratio=0.5, patchsize=16,
+                 use_PatchShuffle_w_Classmix=False, use_PatchShuffle_w_Cutmix=False, no_pos_embed=False, avg_pos_emd=False,
+                 duplicate_pos_emd=False, adaptive_attn_mask=False, attn_mask_weight=50, attn_mask_seperate_head=False,
+                 attn_mask_w_fdrop=False, negative_class_ranking=False, negative_class_ranking_mode='sup_only',
+                 use_fdrop=False, unimatch=False, fdrop_loss_weight=0.5, use_cutmix_adaptive=False,
+                 plain_mt_pseudo_loss=False):
+        super().__init__(init_cfg)
+        lcl = locals()
+        bad = [k for k in _UNSUPPORTED_TRUE if lcl[k]]
+        if bad or neck is not None or projection_head is not None or auxiliary_head_ema is not None \
+                or momentum_head_dropout or momentum_head_exp or momentum_exp or unsup_temperature != 1.0:
+            raise S4FError(f'options outside the hot-path scope of this build (SURVEY §8, "next" rows): {bad}')
+        if pretrained is not None:
+            assert backbone.get('pretrained') is None, 'both backbone and segmentor set pretrained weight'
+            backbone = dict(backbone, pretrained=pretrained)
+        self.backbone = build_backbone(backbone)
+        self._init_decode_head(decode_head)
+        self._init_auxiliary_head(auxiliary_head)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.unsup_weight, self.unsup_confidence = unsup_weight, unsup_confidence
+        self.iter_unsup_start = iter_unsup_start
+        self.ema, self.momentum = ema, ema_momentum
+        self.momentum_backbone = momentum_backbone if momentum_backbone is not None else ema_momentum
+        self.momentum_head = momentum_head if momentum_head is not None else ema_momentum
+        self.patchsize, self.PatchMix_N = patchsize, PatchMix_N
+        self.fdrop_loss_weight = fdrop_loss_weight
+        self.attn_mask_weight, self.adaptive_attn_mask = attn_mask_weight, adaptive_attn_mask
+        self.attn_mask_seperate_head = attn_mask_seperate_head
+        # extension (documented in DESIGN.md): the literal MT config never produces an unsupervised loss (Q1);
+        # True runs compute_pseudo_loss on the plain mean-teacher branch as encoder_decoder.py:681-685 would.
+        self.plain_mt_pseudo_loss = plain_mt_pseudo_loss
+        self.with_auxiliary_head_ema = False
+        if self.ema:
+            if self.momentum_backbone != self.momentum_head:
+                raise S4FError('one EMA launch covers backbone and head: momentum_backbone must equal momentum_head')
+            self._init_ema_model(pretrained, backbone_ema, decode_head_ema)
+        assert self.with_decode_head
+        self.current_iter = 0
+        self.last_mask_ratio = None
+        self._student_store = None
+        self._teacher_store = None
+
+    # ------------------------------------------------------------------ construction
+    def _init_ema_model(self, pretrained, backbone_ema, decode_head_ema):
+        if pretrained is not None:
+            backbone_ema = dict(backbone_ema, pretrained=pretrained)
+        self.backbone_ema = build_backbone(backbone_ema)
+        for p_ in self.backbone_ema.parameters():
+            p_.detach_()
+        self.decode_head_ema = build_head(decode_head_ema)
+        for p_ in self.decode_head_ema.parameters():
+            p_.detach_()
+
+    def _init_decode_head(self, decode_head):
+        self.decode_head = build_head(decode_head)
+        self.align_corners = self.decode_head.align_corners
+        self.num_classes = self.decode_head.num_classes
+
+    def _init_auxiliary_head(self, auxiliary_head):
+        if auxiliary_head is not None:
+            if isinstance(auxiliary_head, list):
+                self.auxiliary_head = nn.ModuleList([build_head(c) for c in auxiliary_head])
+            else:
+                self.auxiliary_head = build_head(auxiliary_head)
+
+    # ------------------------------------------------------------------ arenas
+    def _aux_list(self):
+        if not self.with_auxiliary_head:
+            return []
+        return list(self.auxiliary_head) if isinstance(self.auxiliary_head, nn.ModuleList) else [self.auxiliary_head]
+
+    def _build_stores(self):
+        groups = [('backbone', self.backbone, 'backbone'), ('decode_head', self.decode_head, 'decode_head')]
+        aux = self._aux_list()
+        for i, a in enumerate(aux):
+            pre = f'auxiliary_head.{i}' if isinstance(self.auxiliary_head, nn.ModuleList) else 'auxiliary_head'
+            groups.append((f'auxiliary_head.{i}', a, pre))
+        self._student_store = ParamStore(groups, with_grad=True)
+        self.backbone._attach_store(self._student_store)
+        self.decode_head._attach_store(self._student_store)
+        for a in aux:
+            a._attach_store(self._student_store)
+        if self.ema:
+            self._teacher_store = ParamStore([('backbone', self.backbone_ema, 'backbone_ema'),
+                                              ('decode_head', self.decode_head_ema, 'decode_head_ema')], with_grad=False)
+            self.backbone_ema._attach_store(self._teacher_store)
+            self.decode_head_ema._attach_store(self._teacher_store)
+            n_t = self._teacher_store.total
+            s_sig = [s for s in self._student_store.layout_signature() if s[1] < n_t]
+            if s_sig != self._teacher_store.layout_signature():
+                raise S4FError('teacher and student arenas do not line up (backbone_ema/decode_head_ema must mirror '
+                               'backbone/decode_head)')
+
+    def ensure_engine(self, device):
+        """(re)build the flat arenas after the model has been moved to `device`; refresh bf16 shadows if stale."""
+        if self._student_store is None:
+            self._build_stores()
+        code = runtime.compute_dtype()
+        self._student_store.ensure(device, code)
+        self._student_store.ensure_grads()
+        self._student_store.sync_shadow()
+        if self._teacher_store is not None:
+            self._teacher_store.ensure(device, code)
+            self._teacher_store.sync_shadow()
+        return self._student_store, self._teacher_store
+
+    @property
+    def student_store(self):
+        return self._student_store
+
+    @property
+    def teacher_store(self):
+        return self._teacher_store
+
+    # ------------------------------------------------------------------ feature extraction / heads
+    def extract_feat(self, img, no_pos_embed=False, avg_pos_emd=False, duplicate_pos_emd=False, use_fdrop=False,
+                     attn_mask=None, attn_mask_weight=5, adaptive_attn_mask=False):
+        return self.backbone(img, no_pos_embed=no_pos_embed, avg_pos_emd=avg_pos_emd, duplicate_pos_emd=duplicate_pos_emd,
+                             use_fdrop=use_fdrop, attn_mask=attn_mask, attn_mask_weight=attn_mask_weight,
+                             adaptive_attn_mask=adaptive_attn_mask)
+
+    def extract_feat_ema(self, img):
+        return self.backbone_ema(img)
+
+    def _decode_head_forward_train(self, x, img_metas, gt_semantic_seg):
+        return add_prefix(self.decode_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), 'decode')
+
+    def _auxiliary_head_forward_train(self, x, img_metas, gt_semantic_seg):
+        losses = dict()
+        if isinstance(self.auxiliary_head, nn.ModuleList):
+            for idx, aux_head in enumerate(self.auxiliary_head):
+                losses.update(add_prefix(aux_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), f'aux_{idx}'))
+        else:
+            losses.update(add_prefix(self.auxiliary_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), 'aux'))
+        return losses
+
+    # ------------------------------------------------------------------ EMA
+    def update_ema_variables(self, model=None, ema_model=None, momentum=None, dropout=0.0, attn_frozen=False):
+        """encoder_decoder.py:1044-1066 for (backbone, decode_head incl. BN running stats) in ONE launch over the
+        arenas; the per-module signature of the reference is accepted and ignored."""
+        s, t = self._student_store, self._teacher_store
+        m = self.momentum_backbone if momentum is None else momentum
+        K.ema(t.flat, s.flat, t.flat_t, t.total, m, t.dtype)
+
+    def set_eval(self, ema=False):
+        mods = [self.backbone_ema, self.decode_head_ema] if ema else [self.backbone, self.decode_head] + self._aux_list()
+        for m in mods:
+            m.eval()
+
+    def set_train(self, ema=False):
+        mods = [self.backbone_ema, self.decode_head_ema] if ema else [self.backbone, self.decode_head] + self._aux_list()
+        for m in mods:
+            m.train()
+
+    # ------------------------------------------------------------------ training
+    def forward_train(self, img, img_metas, **kwargs):
+        """encoder_decoder.py:386-514"""
+        if not img.is_cuda:
+            raise S4FError('the S4Former step runs on the MI355X HIP kernels only: move model and batch to the GPU')
+        self.ensure_engine(img.device)
+        current_iter = kwargs.pop('iter')
+        self.current_iter = current_iter
+        kwargs.update({'img': img, 'img_metas': img_metas, 'tag': [meta['tag'] for meta in img_metas]})
+        data_groups = dict_split(kwargs, 'tag')
+        for _, v in data_groups.items():
+            v.pop('tag')
+
+        self.losses = dict()
+        if self.ema:
+            with torch.no_grad():
+                self.update_ema_variables()
+
+        sup_imgs = sup_gts = None
+        if 'sup' in data_groups:
+            sup_imgs = data_groups['sup']['img']
+            sup_gts = data_groups['sup']['gt_semantic_seg']
+            labeled_features = self.extract_feat(sup_imgs)
+            loss_decode_sup = self._decode_head_forward_train(labeled_features, data_groups['sup']['img_metas'], sup_gts)
+            if self.with_auxiliary_head:
+                self.losses.update(self._auxiliary_head_forward_train(labeled_features, data_groups['sup']['img_metas'], sup_gts))
+            self.losses.update(loss_decode_sup)
+
+        if ('unsup_student' in data_groups) and self.unsup_weight != 0:
+            unsup_loss = weighted_loss(
+                self.foward_unsup_train(data_groups['unsup_teacher'], data_groups['unsup_student'], sup_imgs, sup_gts),
+                weight=self.unsup_weight)
+            if self.iter_unsup_start != 0:
+                if current_iter > self.iter_unsup_start:
+                    self.losses.update(unsup_loss)
+            else:
+                self.losses.update(unsup_loss)
+        return self.losses
+
+    def _conf_to_patch_u(self, conf_mask):
+        """encoder_decoder.py:547-555: per-patch mean of (1 - conf) -> [B, gh, gw] (Q12: square crops)"""
+        ps = self.patchsize
+        Bn, H, W = conf_mask.shape
+        c = conf_mask.view(Bn, H // ps, ps, W // ps, ps).to(torch.float32)
+        return (1.0 - c).sum(dim=(2, 4)) / (ps * ps)
+
+    def foward_unsup_train(self, teacher_data, student_data, sup_imgs, sup_gts):
+        """encoder_decoder.py:516-687 (mean-teacher branch; the in-model strong augmentations are 'next' rows)"""
+        loss_unsup = {}
+        tnames = [meta['filename'] for meta in teacher_data['img_metas']]
+        snames = [meta['filename'] for meta in student_data['img_metas']]
+        tidx = [tnames.index(name) for name in snames]
+        timg = teacher_data['img']
+        if tidx != list(range(len(tidx))):
+            timg = timg[torch.tensor(tidx, device=timg.device)]
+        with torch.no_grad():
+            self.set_eval(self.ema)
+            if not self.ema:
+                raise S4FError('the teacher of this build is the EMA model (ema=True in all three SETR configs)')
+            teacher_info = self.extract_teacher_info_ema(timg, [teacher_data['img_metas'][i] for i in tidx])
+            self.set_train(self.ema)
+        # (hard_seg_label already carries 255 where conf_mask == 0: encoder_decoder.py:541-542 is fused in K15)
+        student_info = dict(img=student_data['img'], img_metas=student_data['img_metas'])
+
+        if self.attn_mask_seperate_head:
+            attn_mask = self._conf_to_patch_u(teacher_info['conf_mask'])
+            feat = self.extract_feat(student_info['img'], attn_mask=attn_mask, attn_mask_weight=self.attn_mask_weight,
+                                     adaptive_attn_mask=self.adaptive_attn_mask)
+            student_info['backbone_feature'] = feat
+            loss_unsup['loss_seg_unsup_attn_mask'] = self.compute_pseudo_loss(student_info, teacher_info)['loss_seg_unsup'] * 0.5
+            feat = self.extract_feat(student_info['img'])
+            student_info['backbone_feature'] = feat
+        elif self.plain_mt_pseudo_loss:
+            attn_mask = self._conf_to_patch_u(teacher_info['conf_mask'])
+            feat = self.extract_feat(student_info['img'], attn_mask=attn_mask, attn_mask_weight=self.attn_mask_weight,
+                                     adaptive_attn_mask=self.adaptive_attn_mask)
+            student_info['backbone_feature'] = feat
+        else:
+            # literal MT config (Q1): the reference runs this student forward and throws the result away; it has no
+            # side effect (backbone only, no BN), so it is skipped here.
+            return loss_unsup
+
+        if self.attn_mask_seperate_head or self.plain_mt_pseudo_loss:
+            losses = self.compute_pseudo_loss(student_info, teacher_info)
+            loss_unsup['loss_seg_unsup'] = losses['loss_seg_unsup'] * self.fdrop_loss_weight
+        return loss_unsup
+
+    def extract_teacher_info_ema(self, img, img_metas, unsup_confidence=None):
+        """encoder_decoder.py:875-904: teacher forward (eval-mode BN), softmax / max / threshold fused into one
+        kernel: hard_seg_label uint8 (255 where not confident), conf_mask uint8 {0,1}."""
+        th = self.unsup_confidence if unsup_confidence is None else unsup_confidence
+        feat = self.extract_feat_ema(img)
+        logits_lo, (Bn, h, w) = self.decode_head_ema.logits_lowres(feat)
+        s = self.decode_head_ema.up_scale
+        label = torch.empty(Bn, h * s, w * s, device=img.device, dtype=torch.uint8)
+        conf = torch.empty(Bn, h * s, w * s, device=img.device, dtype=torch.uint8)
+        cnt = torch.zeros(1, device=img.device, dtype=torch.int64)
+        K.up_pseudo_label(logits_lo, label, conf, cnt, th, Bn, h, w, self.num_classes, LOGIT_LD, s)
+        return dict(backbone_feature=feat, seg_logits_lowres=logits_lo, hard_seg_label=label, conf_mask=conf,
+                    conf_count=cnt, img_metas=img_metas)
+
+    def compute_pseudo_loss(self, student_info, teacher_info):
+        """encoder_decoder.py:906-934 (hard labels): mean over ALL pixels of CE(student logits, pseudo labels with
+        ignore 255); mask_ratio = sum(conf) / numel (kept on the device in self.last_mask_ratio)."""
+        loss = self.decode_head.fused_loss(student_info['backbone_feature'], teacher_info['hard_seg_label'], 1.0)
+        out = {'loss_seg_unsup': loss}
+        if self.unsup_confidence != 0:
+            numel = teacher_info['hard_seg_label'].numel()
+            self.last_mask_ratio = teacher_info['conf_count'].to(torch.float32) / numel
+            out['mask_ratio'] = self.last_mask_ratio
+        return out

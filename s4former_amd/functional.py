@@ -1,0 +1,340 @@
+"""Coarse-grained autograd nodes of the hot path.  Each node is a fixed sequence of C-ABI kernel launches with a
+hand-written backward; parameter gradients are accumulated by the kernels straight into the flat gradient
+arena (ParamStore.grad) and the node returns None for them, so a step costs ~20 autograd nodes instead of
+the reference's several hundred ATen ops per pass (SURVEY §7 "host overhead").
+
+Reference semantics restated here:
+  PatchEmbedFn   models/utils/embed.py:183-204 + vit.py:486-487,445 (cls concat, + pos_embed)
+  LayerFn        vit.py:113-127 TransformerEncoderLayer (LN -> MHA -> +x ; LN -> FFN(GELU erf) -> +x)
+  HeadLossFn     setr_up_head.py:92-111 + decode_head.py:318-355 + cross_entropy_loss.py:45-61 (mean over ALL
+                 pixels, Q5).  conv_seg is applied before the last bilinear upsample (they commute: both
+                 linear, interpolation weights sum to 1) and the upsample is fused into the CE kernels.
+"""
+import torch
+import torch.distributed as dist
+from torch.autograd import Function
+
+from . import kernels as K
+from ._lib import BF16, F32, S4FError
+
+LOGIT_LD = 32   # channel stride of the low-resolution logits buffers (>= num_classes, multiple of 8)
+
+
+def _T(code):
+    return torch.bfloat16 if code == BF16 else torch.float32
+
+
+def _splitk(tiles, nk, target=512):
+    sk = max(1, target // max(1, tiles))
+    return int(max(1, min(sk, max(1, nk // 4))))
+
+
+def _tiles(m, n):
+    return ((m + 127) // 128) * ((n + 127) // 128)
+
+
+def _nk(k, code):
+    bk = 64 if code == BF16 else 32
+    return (k + bk - 1) // bk
+
+
+def _as_T(x_f32, code):
+    """operand-typed copy of an fp32 tensor (identity in parity mode)"""
+    if code == F32:
+        return x_f32
+    cached = getattr(x_f32, '_s4f_t', None)
+    if cached is not None and cached[1] == x_f32._version and cached[2] == x_f32.data_ptr():
+        return cached[0]
+    out = torch.empty(x_f32.shape, device=x_f32.device, dtype=torch.bfloat16)
+    K.cast(x_f32, out, BF16)
+    return out
+
+
+def _wgrad(dy, x, M, N, rows, ldm, ldn, out, code):
+    """out[M,N] += dy[rows,M]^T x[rows,N]   (fp32 atomic accumulate into the gradient arena)"""
+    K.gemm(dy, x, M, N, rows, ldm, ldn, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=out, ldo_f32=N, atomic=True,
+           splitk=_splitk(_tiles(M, N), _nk(rows, code)))
+
+
+# ============================================================================================== patch embed
+class PatchEmbedFn(Function):
+    @staticmethod
+    def forward(ctx, img, w, b, cls, pos, store):
+        code = store.dtype
+        Bn, _, H, W = img.shape
+        E = w.shape[0]
+        ntok = (H // 16) * (W // 16) + 1
+        if pos.shape[1] != ntok:
+            raise S4FError(f'pos_embed has {pos.shape[1]} tokens, input needs {ntok} (resize is an inference-only path)')
+        cols = torch.zeros(Bn * ntok, 768, device=img.device, dtype=_T(code))
+        K.im2col_patch16(img, cols, code, pad_cls=True)
+        tokens = torch.empty(Bn, ntok, E, device=img.device, dtype=torch.float32)
+        posf = store.phys(pos)
+        K.gemm(cols, store.shadow(w), Bn * ntok, E, 768, 768, 768, code, bias=store.phys(b), out_f32=tokens, ldo_f32=E,
+               pos_period=ntok, pos=posf)
+        K.cls_pos(store.phys(cls), posf, tokens)
+        ctx.store, ctx.cols, ctx.dims = store, cols, (Bn, ntok, E)
+        ctx.prm = (w, b, cls, pos)
+        return tokens
+
+    @staticmethod
+    def backward(ctx, dtok):
+        store, cols = ctx.store, ctx.cols
+        code = store.dtype
+        Bn, ntok, E = ctx.dims
+        w, b, cls, pos = ctx.prm
+        dtok = dtok.contiguous()
+        dt_t = _as_T(dtok, code)
+        _wgrad(dt_t, cols, E, 768, Bn * ntok, E, 768, store.grad_phys(w), code)
+        K.colsum(dtok, E, Bn * ntok, E, store.grad_phys(b), F32, skip_period=ntok)
+        K.tokens_bwd(dtok, store.grad_phys(pos), store.grad_phys(cls))
+        ctx.cols = None
+        store.node_done()
+        return None, None, None, None, None, None
+
+
+# ============================================================================================== encoder layer
+class LayerFn(Function):
+    """x [B,N,E] fp32 -> x + MHA(LN1(x)) -> (+ FFN(LN2(.)))   (vit.py:113-127)"""
+
+    @staticmethod
+    def forward(ctx, x, bias_u, row_flag, bias_w, num_heads, eps, store, *prm):
+        (g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, bf1, w2, bf2) = prm
+        code = store.dtype
+        T = _T(code)
+        Bn, N, E = x.shape
+        M = Bn * N
+        F_ = w1.shape[0]
+        dev = x.device
+        x = x.contiguous()
+        xn = torch.empty(M, E, device=dev, dtype=T)
+        mean1 = torch.empty(M, device=dev); rstd1 = torch.empty(M, device=dev)
+        K.layernorm_fwd(x, store.phys(g1), store.phys(b1), xn, mean1, rstd1, M, E, code, eps)
+        qkv = torch.empty(M, 3 * E, device=dev, dtype=T)
+        K.gemm(xn, store.shadow(wqkv), M, 3 * E, E, E, E, code, bias=store.phys(bqkv), out_t=qkv, ldo_t=3 * E)
+        ctxv = torch.empty(M, E, device=dev, dtype=T)
+        lse = torch.empty(Bn, num_heads, N, device=dev)
+        K.attention_fwd(qkv, ctxv, lse, Bn, N, num_heads, code, bias_u=bias_u, row_flag=row_flag, bias_w=bias_w)
+        x1 = torch.empty(Bn, N, E, device=dev)
+        K.gemm(ctxv, store.shadow(wo), M, E, E, E, E, code, bias=store.phys(bo), resid=x, ldr=E, out_f32=x1, ldo_f32=E)
+        xn2 = torch.empty(M, E, device=dev, dtype=T)
+        mean2 = torch.empty(M, device=dev); rstd2 = torch.empty(M, device=dev)
+        K.layernorm_fwd(x1, store.phys(g2), store.phys(b2), xn2, mean2, rstd2, M, E, code, eps)
+        z = torch.empty(M, F_, device=dev, dtype=T)
+        a = torch.empty(M, F_, device=dev, dtype=T)
+        K.gemm(xn2, store.shadow(w1), M, F_, E, E, E, code, bias=store.phys(bf1), out_t=a, ldo_t=F_, out_pre=z, ldo_pre=F_,
+               act=K.ACT_GELU)
+        x2 = torch.empty(Bn, N, E, device=dev)
+        K.gemm(a, store.shadow(w2), M, E, F_, F_, F_, code, bias=store.phys(bf2), resid=x1, ldr=E, out_f32=x2, ldo_f32=E)
+        if any(ctx.needs_input_grad):
+            ctx.store, ctx.prm = store, prm
+            ctx.cfg = (Bn, N, E, F_, num_heads, bias_w)
+            ctx.sv = dict(x=x, xn=xn, mean1=mean1, rstd1=rstd1, qkv=qkv, ctxv=ctxv, lse=lse, x1=x1, xn2=xn2, mean2=mean2,
+                          rstd2=rstd2, z=z, a=a, bias_u=bias_u, row_flag=row_flag)
+        return x2
+
+    @staticmethod
+    def backward(ctx, g2):
+        store = ctx.store
+        code = store.dtype
+        T = _T(code)
+        (gm1, b1, wqkv, bqkv, wo, bo, gm2, b2, w1, bf1, w2, bf2) = ctx.prm
+        Bn, N, E, F_, H, bias_w = ctx.cfg
+        sv = ctx.sv
+        M = Bn * N
+        dev = g2.device
+        g2 = g2.contiguous()
+        g2t = _as_T(g2, code)
+        # ---- FFN
+        _wgrad(g2t, sv['a'], E, F_, M, E, F_, store.grad_phys(w2), code)
+        K.colsum(g2t, E, M, E, store.grad_phys(bf2), code)
+        dz = torch.empty(M, F_, device=dev, dtype=T)
+        K.gemm(g2t, store.shadow(w2), M, F_, E, E, F_, code, b_mode=K.OP_K, out_t=dz, ldo_t=F_, aux=sv['z'], ld_aux=F_,
+               act=K.ACT_GELU_BWD)
+        sv['z'] = sv['a'] = None
+        _wgrad(dz, sv['xn2'], F_, E, M, F_, E, store.grad_phys(w1), code)
+        K.colsum(dz, F_, M, F_, store.grad_phys(bf1), code)
+        dxn2 = torch.empty(M, E, device=dev, dtype=T)
+        K.gemm(dz, store.shadow(w1), M, E, F_, F_, E, code, b_mode=K.OP_K, out_t=dxn2, ldo_t=E)
+        del dz
+        g1 = torch.empty(Bn, N, E, device=dev)
+        g1t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
+        K.layernorm_bwd(dxn2, sv['x1'], sv['mean2'], sv['rstd2'], store.phys(gm2), g2, g1, g1t, store.grad_phys(gm2),
+                        store.grad_phys(b2), M, E, code)
+        if g1t is None:
+            g1t = g1
+        # ---- attention
+        _wgrad(g1t, sv['ctxv'], E, E, M, E, E, store.grad_phys(wo), code)
+        K.colsum(g1t, E, M, E, store.grad_phys(bo), code)
+        dctx = torch.empty(M, E, device=dev, dtype=T)
+        K.gemm(g1t, store.shadow(wo), M, E, E, E, E, code, b_mode=K.OP_K, out_t=dctx, ldo_t=E)
+        dqkv = torch.empty(M, 3 * E, device=dev, dtype=T)
+        delta = torch.empty(Bn, H, N, device=dev)
+        K.attention_bwd(sv['qkv'], sv['ctxv'], dctx, sv['lse'], delta, dqkv, Bn, N, H, code, bias_u=sv['bias_u'],
+                        row_flag=sv['row_flag'], bias_w=bias_w)
+        _wgrad(dqkv, sv['xn'], 3 * E, E, M, 3 * E, E, store.grad_phys(wqkv), code)
+        K.colsum(dqkv, 3 * E, M, 3 * E, store.grad_phys(bqkv), code)
+        dxn = torch.empty(M, E, device=dev, dtype=T)
+        K.gemm(dqkv, store.shadow(wqkv), M, E, 3 * E, 3 * E, E, code, b_mode=K.OP_K, out_t=dxn, ldo_t=E)
+        del dqkv
+        g0 = torch.empty(Bn, N, E, device=dev)
+        g0t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
+        K.layernorm_bwd(dxn, sv['x'], sv['mean1'], sv['rstd1'], store.phys(gm1), g1, g0, g0t, store.grad_phys(gm1),
+                        store.grad_phys(b1), M, E, code)
+        if g0t is not None:
+            # reused by the previous layer if autograd hands this very tensor through unmodified (autograd may
+            # accumulate other branches into it in place: the version counter catches that)
+            g0._s4f_t = (g0t, g0._version, g0.data_ptr())
+        ctx.sv = None
+        store.node_done()
+        return (g0,) + (None,) * (6 + 12)
+
+
+# ============================================================================================== SETR-PUP head
+def _world():
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def head_forward(tokens, hp, store, training, save):
+    """LN -> [conv3x3 -> (Sync)BN -> ReLU -> up]*n -> conv_seg (before the last upsample) -> low-res logits.
+    tokens: fp32 [B, T+1, E] (cls first; dropped here).  hp: dict with the head's parameters/buffers/config.
+    Returns (logits_lo fp32 [B*h*w, LOGIT_LD], (B, h, w), saved or None)."""
+    code = store.dtype
+    T = _T(code)
+    Bn, ntok, E = tokens.shape
+    dev = tokens.device
+    gh, gw = hp['grid']
+    if gh * gw + 1 != ntok:
+        raise S4FError(f'head: token count {ntok} does not match the patch grid {gh}x{gw}')
+    rows = Bn * gh * gw
+    xn = torch.empty(rows, E, device=dev, dtype=T)
+    mean0 = torch.empty(rows, device=dev); rstd0 = torch.empty(rows, device=dev)
+    tv = tokens[:, 1:]
+    K.layernorm_fwd(tv, store.phys(hp['norm_w']), store.phys(hp['norm_b']), xn, mean0, rstd0, rows, E, code, hp['ln_eps'],
+                    rows_per_img=gh * gw, in_batch_stride=ntok * E)
+    sv = dict(tokens=tokens, mean0=mean0, rstd0=rstd0, stages=[]) if save else None
+    cur, h, w, cin = xn, gh, gw, E
+    nconv = len(hp['convs'])
+    world = _world() if (hp['sync_bn'] and training) else 1
+    for k, cv in enumerate(hp['convs']):
+        Cc = cv['w'].shape[0]
+        Mp = Bn * h * w
+        y = torch.empty(Mp, Cc, device=dev, dtype=T)
+        K.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_t=y, ldo_t=Cc,
+               conv=(Bn, h, w, cin, 1))
+        scale = torch.empty(Cc, device=dev); shift = torch.empty(Cc, device=dev)
+        mean = torch.empty(Cc, device=dev); rstd = torch.empty(Cc, device=dev)
+        count = float(Mp) * world
+        if training:
+            sums = torch.zeros(2 * Cc, device=dev)
+            K.bn_stats(y, Mp, Cc, sums, code)
+            if world > 1:
+                dist.all_reduce(sums)
+            K.bn_finalize(sums, count, store.phys(cv['bn_w']), store.phys(cv['bn_b']), store.phys(cv['rm']),
+                          store.phys(cv['rv']), hp['bn_momentum'], hp['bn_eps'], True, scale, shift, mean, rstd, Cc)
+            cv['nbt'][0] += 1
+        else:
+            K.bn_finalize(None, 0, store.phys(cv['bn_w']), store.phys(cv['bn_b']), store.phys(cv['rm']),
+                          store.phys(cv['rv']), hp['bn_momentum'], hp['bn_eps'], False, scale, shift, mean, rstd, Cc)
+        s = hp['up_scale'] if k < nconv - 1 else 1
+        u = torch.empty(Bn * h * s * w * s, Cc, device=dev, dtype=T)
+        K.bn_relu_up_fwd(y, scale, shift, u, Bn, h, w, Cc, s, code)
+        if save:
+            sv['stages'].append(dict(inp=cur, y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, h=h, w=w, s=s, cin=cin,
+                                     count=count, Cc=Cc))
+        cur, h, w, cin = u, h * s, w * s, Cc
+    ncls = hp['num_classes']
+    Mp = Bn * h * w
+    logits = torch.zeros(Mp, LOGIT_LD, device=dev)
+    K.gemm(cur, store.shadow(hp['seg_w']), Mp, ncls, cin, cin, cin, code, bias=store.phys(hp['seg_b']), out_f32=logits,
+           ldo_f32=LOGIT_LD)
+    if save:
+        sv['feat'] = cur
+        sv['logits'] = logits
+    return logits, (Bn, h, w), sv
+
+
+def head_backward(dlo, dlo_t, sv, hp, store):
+    """gradients of everything upstream of the low-res logits; returns d tokens (fp32 [B, T+1, E])."""
+    code = store.dtype
+    T = _T(code)
+    tokens = sv['tokens']
+    Bn, ntok, E = tokens.shape
+    dev = tokens.device
+    ncls = hp['num_classes']
+    feat = sv['feat']
+    cin = feat.shape[1]
+    Mp = feat.shape[0]
+    # conv_seg: dW[ncls, cin] += dlo^T feat ; db += colsum(dlo) ; dfeat = dlo W
+    K.gemm(dlo_t, feat, ncls, cin, Mp, LOGIT_LD, cin, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=store.grad_phys(hp['seg_w']),
+           ldo_f32=cin, atomic=True, splitk=_splitk(_tiles(ncls, cin), _nk(Mp, code), target=1024))
+    K.colsum(dlo, LOGIT_LD, Mp, ncls, store.grad_phys(hp['seg_b']), F32)
+    dcur = torch.empty(Mp, cin, device=dev, dtype=T)
+    K.gemm(dlo_t, store.shadow(hp['seg_w']), Mp, cin, ncls, LOGIT_LD, cin, code, b_mode=K.OP_K, out_t=dcur, ldo_t=cin)
+    world = _world() if hp['sync_bn'] else 1
+    for k in range(len(hp['convs']) - 1, -1, -1):
+        cv, st = hp['convs'][k], sv['stages'][k]
+        Cc, h, w, s, cin_k = st['Cc'], st['h'], st['w'], st['s'], st['cin']
+        Mk = Bn * h * w
+        g = torch.empty(Mk, Cc, device=dev, dtype=T)
+        bsums = torch.zeros(2 * Cc, device=dev)
+        K.bn_relu_up_bwd(dcur, st['y'], st['scale'], st['shift'], st['mean'], st['rstd'], g, bsums, Bn, h, w, Cc, s, code)
+        K.bn_param_grads(bsums, store.grad_phys(cv['bn_w']), store.grad_phys(cv['bn_b']), Cc)
+        if world > 1:
+            dist.all_reduce(bsums)
+        dy = torch.empty(Mk, Cc, device=dev, dtype=T)
+        K.bn_bwd_apply(g, st['y'], st['mean'], st['rstd'], store.phys(cv['bn_w']), bsums, st['count'], dy, Mk, Cc, code)
+        del g
+        st['y'] = None
+        # conv weight gradient [Cc][3][3][cin] += dy^T (shifted inp)
+        K.gemm(dy, st['inp'], Cc, 9 * cin_k, Mk, Cc, cin_k, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV,
+               out_f32=store.grad_phys(cv['w']), ldo_f32=9 * cin_k, atomic=True,
+               splitk=_splitk(_tiles(Cc, 9 * cin_k), _nk(Mk, code), target=768), conv=(Bn, h, w, cin_k, 1))
+        st['inp'] = None
+        dcur = torch.empty(Mk, cin_k, device=dev, dtype=T)
+        K.gemm(dy, store.shadow(cv['w']), Mk, cin_k, 9 * Cc, Cc, 9 * cin_k, code, a_mode=K.OP_ROW_CONV, b_mode=K.OP_K_TAPSPLIT,
+               out_t=dcur, ldo_t=cin_k, conv=(Bn, h, w, Cc, -1))
+        del dy
+    gh, gw = hp['grid']
+    dtok = torch.zeros(Bn, ntok, E, device=dev)
+    K.layernorm_bwd(dcur, tokens[:, 1:], sv['mean0'], sv['rstd0'], store.phys(hp['norm_w']), None, dtok[:, 1:], None,
+                    store.grad_phys(hp['norm_w']), store.grad_phys(hp['norm_b']), Bn * gh * gw, E, code,
+                    rows_per_img=gh * gw, in_batch_stride=ntok * E)
+    return dtok
+
+
+class HeadLossFn(Function):
+    """loss = loss_weight * mean_all_pixels CE(up_s(logits_lo), labels; ignore 255)   (Q5)"""
+
+    @staticmethod
+    def forward(ctx, tokens, labels_u8, loss_weight, hp, store, *prm):
+        need_grad = any(ctx.needs_input_grad)
+        logits, (Bn, h, w), sv = head_forward(tokens, hp, store, training=hp['training'], save=need_grad)
+        s = hp['up_scale']
+        H, W = h * s, w * s
+        if tuple(labels_u8.shape) != (Bn, H, W):
+            raise S4FError(f'labels {tuple(labels_u8.shape)} do not match the logits size {(Bn, H, W)} '
+                           '(the identity resize of decode_head.py:322-326 is the only one on the hot path)')
+        loss_sum = torch.zeros(1, device=tokens.device)
+        K.upce_fwd(logits, labels_u8, loss_sum, Bn, h, w, hp['num_classes'], LOGIT_LD, s, hp['ignore_index'])
+        k = float(loss_weight) / float(Bn * H * W)
+        if need_grad:
+            ctx.sv, ctx.hp, ctx.store = sv, hp, store
+            ctx.meta = (labels_u8, k, Bn, h, w, s)
+        return (loss_sum * k).reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        sv, hp, store = ctx.sv, ctx.hp, ctx.store
+        labels, k, Bn, h, w, s = ctx.meta
+        code = store.dtype
+        logits = sv['logits']
+        dlo = torch.empty_like(logits)
+        dlo_t = torch.empty(logits.shape, device=logits.device, dtype=torch.bfloat16) if code == BF16 else None
+        gdev = dloss.detach().reshape(1).to(torch.float32).contiguous()
+        K.upce_bwd(logits, labels, k, dlo, dlo_t, Bn, h, w, hp['num_classes'], LOGIT_LD, s, code, hp['ignore_index'],
+                   gscale_dev=gdev)
+        dtok = head_backward(dlo, dlo_t if dlo_t is not None else dlo, sv, hp, store)
+        ctx.sv = None
+        store.node_done()
+        return (dtok, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)

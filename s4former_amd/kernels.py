@@ -27,6 +27,17 @@ def _need(t, n, what):
         raise S4FError(f'{what}: tensor has {t.numel()} elements, kernel touches {n}')
 
 
+def _need_span(t, n, what):
+    """like _need for a (possibly strided) view: n elements must be addressable from its data pointer"""
+    if t is None:
+        return
+    if not t.is_cuda:
+        raise S4FError(f'{what}: expected a device tensor')
+    avail = t.untyped_storage().nbytes() // t.element_size() - t.storage_offset()
+    if avail < n:
+        raise S4FError(f'{what}: {avail} elements addressable, kernel touches {n}')
+
+
 def _tdt(code):
     return torch.bfloat16 if code == BF16 else torch.float32
 
@@ -43,7 +54,7 @@ def _chk_f32(t, what):
 
 def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=1.0, bias=None, resid=None, ldr=0,
          out_f32=None, ldo_f32=0, out_t=None, ldo_t=0, out_pre=None, ldo_pre=0, aux=None, ld_aux=0, act=ACT_NONE,
-         atomic=False, splitk=1, conv=None, rowmap_tpi=0, pos=None):
+         atomic=False, splitk=1, conv=None, pos_period=0, pos=None):
     """C[m,n] = alpha * sum_k A(m,k) B(n,k) + epilogue; see include/s4f.h. conv = (B, H, W, C, sign)."""
     _chk_dtype(A, dtype, 'gemm A'); _chk_dtype(B, dtype, 'gemm B')
     _chk_dtype(out_t, dtype, 'gemm out_t'); _chk_dtype(out_pre, dtype, 'gemm out_pre'); _chk_dtype(aux, dtype, 'gemm aux')
@@ -71,16 +82,14 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
         _need(B, (cB * cH * cW - 1) * ldb + cC, 'gemm B (conv)')
     else:
         raise S4FError(f'bad b_mode {b_mode}')
-    rows_out = M if rowmap_tpi == 0 else M + (M + rowmap_tpi - 1) // rowmap_tpi
-    if rowmap_tpi and M % rowmap_tpi:
-        raise S4FError('gemm: M must be a multiple of rowmap_tpi')
+    rows_out = M
     _need(bias, N, 'gemm bias')
     _need(out_f32, (rows_out - 1) * ldo_f32 + N if out_f32 is not None else 0, 'gemm out_f32')
     _need(out_t, (rows_out - 1) * ldo_t + N if out_t is not None else 0, 'gemm out_t')
     _need(out_pre, (rows_out - 1) * ldo_pre + N if out_pre is not None else 0, 'gemm out_pre')
     _need(resid, (rows_out - 1) * ldr + N if resid is not None else 0, 'gemm resid')
     _need(aux, (M - 1) * ld_aux + N if aux is not None else 0, 'gemm aux')
-    _need(pos, (rowmap_tpi + 1) * N if pos is not None else 0, 'gemm pos')
+    _need(pos, pos_period * N if pos is not None else 0, 'gemm pos')
     d = L.GemmDesc()
     d.A, d.B = p(A), p(B)
     d.M, d.N, d.K = M, N, K
@@ -94,7 +103,7 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
     d.out_pre, d.ldo_pre = p(out_pre), ldo_pre
     d.aux, d.ld_aux = p(aux), ld_aux
     d.act, d.atomic = act, 1 if atomic else 0
-    d.rowmap_tpi, d.pos = rowmap_tpi, p(pos)
+    d.pos_period, d.pos = pos_period, p(pos)
     call('s4f_gemm', ctypes.byref(d), stream())
 
 
@@ -110,13 +119,14 @@ def cast_back(src, dst, dtype):
     call('s4f_cast_back', p(src), p(dst), src.numel(), dtype, stream())
 
 
-def im2col_patch16(img, cols, dtype):
+def im2col_patch16(img, cols, dtype, pad_cls=False):
     B, Cin, H, W = img.shape
     if Cin != 3:
         raise S4FError('im2col_patch16: 3 input channels expected')
     _chk_f32(img, 'im2col img'); _chk_dtype(cols, dtype, 'im2col cols')
-    _need(img, B * 3 * H * W, 'im2col img'); _need(cols, B * (H // 16) * (W // 16) * 768, 'im2col cols')
-    call('s4f_im2col_patch16', p(img), p(cols), B, H, W, dtype, stream())
+    _need(img, B * 3 * H * W, 'im2col img')
+    _need(cols, B * ((H // 16) * (W // 16) + (1 if pad_cls else 0)) * 768, 'im2col cols')
+    call('s4f_im2col_patch16', p(img), p(cols), B, H, W, 1 if pad_cls else 0, dtype, stream())
 
 
 def cls_pos(cls, pos, tokens):
@@ -133,42 +143,48 @@ def tokens_bwd(dtok, dpos, dcls):
     call('s4f_tokens_bwd', p(dtok), p(dpos), p(dcls), B, ntok, C, stream())
 
 
-def colsum(X, ld, M, N, out, dtype):
+def colsum(X, ld, M, N, out, dtype, skip_period=0):
     _chk_dtype(X, dtype, 'colsum X'); _chk_f32(out, 'colsum out')
     _need(X, (M - 1) * ld + N, 'colsum X'); _need(out, N, 'colsum out')
-    call('s4f_colsum', p(X), ld, M, N, p(out), dtype, stream())
+    call('s4f_colsum', p(X), ld, M, N, p(out), skip_period, dtype, stream())
 
 
-def _ln_in_rows(rows, rows_per_img, skip):
-    return rows + (rows // rows_per_img) * skip if skip else rows
+def _ln_extent(rows, C, rows_per_img, bstride):
+    """elements of the input the kernel touches: last image's last row"""
+    nimg = (rows + rows_per_img - 1) // rows_per_img
+    return (nimg - 1) * bstride + rows_per_img * C
 
 
-def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, dtype, eps, rows_per_img=0, skip=0):
-    if skip and rows % rows_per_img:
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, dtype, eps, rows_per_img=0, in_batch_stride=0):
+    """x may be a strided view (e.g. tokens[:, 1:]): only its data pointer and in_batch_stride are used."""
+    if rows_per_img <= 0:
+        rows_per_img, in_batch_stride = rows, 0
+    if rows % rows_per_img:
         raise S4FError('layernorm_fwd: rows must be a multiple of rows_per_img')
     _chk_f32(x, 'ln x'); _chk_f32(gamma, 'ln gamma'); _chk_f32(beta, 'ln beta'); _chk_dtype(y, dtype, 'ln y')
     _chk_f32(mean, 'ln mean'); _chk_f32(rstd, 'ln rstd')
-    _need(x, _ln_in_rows(rows, rows_per_img, skip) * C, 'ln x'); _need(y, rows * C, 'ln y')
+    _need_span(x, _ln_extent(rows, C, rows_per_img, in_batch_stride), 'ln x'); _need(y, rows * C, 'ln y')
     _need(gamma, C, 'ln gamma'); _need(beta, C, 'ln beta'); _need(mean, rows, 'ln mean'); _need(rstd, rows, 'ln rstd')
-    call('s4f_layernorm_fwd', p(x), p(gamma), p(beta), p(y), p(mean), p(rstd), rows, C, rows_per_img, skip, eps, dtype,
-         stream())
+    call('s4f_layernorm_fwd', p(x), p(gamma), p(beta), p(y), p(mean), p(rstd), rows, C, rows_per_img, in_batch_stride,
+         eps, dtype, stream())
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dresid, dx, dx_t, dgamma, dbeta, rows, C, dtype, rows_per_img=0, skip=0,
-                  accumulate=False):
-    if skip and rows % rows_per_img:
+def layernorm_bwd(dy, x, mean, rstd, gamma, dresid, dx, dx_t, dgamma, dbeta, rows, C, dtype, rows_per_img=0,
+                  in_batch_stride=0, accumulate=False):
+    if rows_per_img <= 0:
+        rows_per_img, in_batch_stride = rows, 0
+    if rows % rows_per_img:
         raise S4FError('layernorm_bwd: rows must be a multiple of rows_per_img')
-    nin = _ln_in_rows(rows, rows_per_img, skip) * C
+    nin = _ln_extent(rows, C, rows_per_img, in_batch_stride)
     _chk_dtype(dy, dtype, 'ln_bwd dy'); _chk_dtype(dx_t, dtype, 'ln_bwd dx_t')
     for t in (x, mean, rstd, gamma, dresid, dx, dgamma, dbeta):
         _chk_f32(t, 'ln_bwd')
-    _need(dy, rows * C, 'ln_bwd dy'); _need(x, nin, 'ln_bwd x'); _need(dx, nin, 'ln_bwd dx')
-    _need(dresid, nin if dresid is not None else 0, 'ln_bwd dresid')
-    _need(dx_t, nin if dx_t is not None else 0, 'ln_bwd dx_t')
+    _need(dy, rows * C, 'ln_bwd dy'); _need_span(x, nin, 'ln_bwd x'); _need_span(dx, nin, 'ln_bwd dx')
+    _need_span(dresid, nin, 'ln_bwd dresid'); _need_span(dx_t, nin, 'ln_bwd dx_t')
     _need(mean, rows, 'ln_bwd mean'); _need(rstd, rows, 'ln_bwd rstd')
     _need(gamma, C, 'ln_bwd gamma'); _need(dgamma, C, 'ln_bwd dgamma'); _need(dbeta, C, 'ln_bwd dbeta')
     call('s4f_layernorm_bwd', p(dy), p(x), p(mean), p(rstd), p(gamma), p(dresid), p(dx), p(dx_t), p(dgamma), p(dbeta),
-         rows, C, rows_per_img, skip, 1 if accumulate else 0, dtype, stream())
+         rows, C, rows_per_img, in_batch_stride, 1 if accumulate else 0, dtype, stream())
 
 
 def add_f32(a, b, out, out_t, dtype):
@@ -267,13 +283,14 @@ def upce_fwd(logits_lo, labels, loss_sum, B, h, w, C, ldc, s, ignore_index=255):
     call('s4f_upce_fwd', p(logits_lo), p(labels), p(loss_sum), B, h, w, C, ldc, s, ignore_index, stream())
 
 
-def upce_bwd(logits_lo, labels, gscale, dlo, dlo_t, B, h, w, C, ldc, s, dtype, ignore_index=255):
+def upce_bwd(logits_lo, labels, gscale, dlo, dlo_t, B, h, w, C, ldc, s, dtype, ignore_index=255, gscale_dev=None):
     _chk_f32(logits_lo, 'upce_bwd logits'); _need(logits_lo, B * h * w * ldc, 'upce_bwd logits')
     _chk_u8(labels, B * h * s * w * s, 'upce_bwd labels')
     _chk_f32(dlo, 'upce_bwd dlo'); _need(dlo, B * h * w * ldc, 'upce_bwd dlo')
     _chk_dtype(dlo_t, dtype, 'upce_bwd dlo_t'); _need(dlo_t, B * h * w * ldc if dlo_t is not None else 0, 'upce_bwd dlo_t')
-    call('s4f_upce_bwd', p(logits_lo), p(labels), float(gscale), p(dlo), p(dlo_t), B, h, w, C, ldc, s, ignore_index,
-         dtype, stream())
+    _chk_f32(gscale_dev, 'upce_bwd gscale_dev'); _need(gscale_dev, 1 if gscale_dev is not None else 0, 'upce_bwd gscale_dev')
+    call('s4f_upce_bwd', p(logits_lo), p(labels), float(gscale), p(gscale_dev), p(dlo), p(dlo_t), B, h, w, C, ldc, s,
+         ignore_index, dtype, stream())
 
 
 def up_pseudo_label(logits_lo, label_out, conf_out, conf_count, th, B, h, w, C, ldc, s):

@@ -1,0 +1,205 @@
+"""Flat parameter arenas (MI355X-first memory layout of the model state).
+
+All parameters (and the BatchNorm running statistics) of a replica live in ONE fp32 arena, with a second arena
+of identical layout for gradients, one for SGD momentum, and a bf16 shadow arena for the MFMA operands.  The
+nn.Parameters the mmseg-style modules expose are views into the arena, so state_dict()/load_state_dict()/
+optimizers keep working, while EMA (reference encoder_decoder.py:1044-1066), SGD and the gradient all-reduce
+each become one launch over a contiguous range instead of a Python loop over ~200 tensors.
+
+3x3 conv weights are stored physically as [co][ky][kx][ci] (torch channels_last strides on the logical
+[co,ci,ky,kx] parameter): that is the B-operand layout of the implicit-GEMM kernels.
+"""
+import torch
+import torch.nn as nn
+
+from . import kernels as K
+from ._lib import BF16, S4FError
+
+ALIGN = 64  # elements
+
+
+def _is_conv3x3(t):
+    return t.dim() == 4 and t.shape[2] == 3 and t.shape[3] == 3
+
+
+class _Entry:
+    __slots__ = ('module', 'attr', 'is_param', 'name', 'group', 'shape', 'numel', 'off', 'cl')
+
+
+class ParamStore:
+    """groups: list of (group_name, module, prefix).  Parameters come first inside each group, then the BN
+    running_mean / running_var buffers (num_batches_tracked stays an ordinary buffer)."""
+
+    def __init__(self, groups, with_grad=True):
+        self.groups = groups
+        self.with_grad = with_grad
+        self.entries = []
+        self.by_id = {}
+        self.flat = self.flat_t = self.grad = self.mom = None
+        self.dtype = None
+        self.group_ranges = {}       # group -> dict(params=(a,b), all=(a,b))
+        self._versions = None
+        self._shadow_dirty = True
+        self.first_sgd_step = True
+        self._collect()
+
+    # ------------------------------------------------------------------ layout
+    def _collect(self):
+        off = 0
+        for gname, module, prefix in self.groups:
+            g0 = off
+            plist = [(n, p_, True) for n, p_ in module.named_parameters()]
+            blist = [(n, b, False) for n, b in module.named_buffers()
+                     if b is not None and b.dtype == torch.float32 and n.split('.')[-1] in ('running_mean', 'running_var')]
+            pend = None
+            for lst in (plist, blist):
+                for n, t, is_param in lst:
+                    e = _Entry()
+                    mod = module
+                    parts = n.split('.')
+                    for s in parts[:-1]:
+                        mod = getattr(mod, s)
+                    e.module, e.attr, e.is_param = mod, parts[-1], is_param
+                    e.name = f'{prefix}.{n}' if prefix else n
+                    e.group = gname
+                    e.shape = tuple(t.shape)
+                    e.numel = t.numel()
+                    e.cl = _is_conv3x3(t)
+                    e.off = off
+                    off += (e.numel + ALIGN - 1) // ALIGN * ALIGN
+                    self.entries.append(e)
+                if lst is plist:
+                    pend = off
+            self.group_ranges[gname] = dict(params=(g0, pend), all=(g0, off))
+        self.total = off
+
+    def _tensor(self, e):
+        return e.module._parameters[e.attr] if e.is_param else e.module._buffers[e.attr]
+
+    def _view(self, arena, e):
+        v = arena[e.off:e.off + e.numel]
+        if e.cl:
+            co, ci, kh, kw = e.shape
+            return v.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return v.view(e.shape)
+
+    def layout_signature(self, upto_group=None):
+        sig = []
+        for e in self.entries:
+            sig.append((e.shape, e.off, e.is_param))
+        return sig
+
+    # ------------------------------------------------------------------ build / validity
+    def build(self, device, dtype_code):
+        """(re)allocate the arenas on `device` and re-point every parameter/buffer into them"""
+        self.dtype = dtype_code
+        flat = torch.zeros(self.total, device=device, dtype=torch.float32)
+        for e in self.entries:
+            src = self._tensor(e).detach()
+            self._view(flat, e).copy_(src.to(device))
+        self.flat = flat
+        self.flat_t = torch.empty(self.total, device=device, dtype=torch.bfloat16) if dtype_code == BF16 else None
+        if self.with_grad:
+            self.grad = torch.zeros(self.total, device=device, dtype=torch.float32)
+            self.mom = torch.zeros(self.total, device=device, dtype=torch.float32)
+        self.by_id = {}
+        for e in self.entries:
+            v = self._view(flat, e)
+            if e.is_param:
+                prm = e.module._parameters[e.attr]
+                prm.data = v
+                if self.with_grad and prm.requires_grad:
+                    prm.grad = self._view(self.grad, e)
+                self.by_id[id(prm)] = e
+            else:
+                e.module._buffers[e.attr] = v
+                self.by_id[id(v)] = e
+        self._shadow_dirty = True
+        self._versions = None
+        self.first_sgd_step = True
+        return self
+
+    def is_valid(self, device):
+        if self.flat is None or self.flat.device != torch.device(device):
+            return False
+        for e in (self.entries[0], self.entries[-1]):
+            t = self._tensor(e)
+            if t.data_ptr() != self.flat.data_ptr() + 4 * e.off:
+                return False
+        return True
+
+    def ensure(self, device, dtype_code):
+        if not self.is_valid(device) or self.dtype != dtype_code:
+            self.build(device, dtype_code)
+        return self
+
+    def ensure_grads(self):
+        """re-attach .grad views (a foreign zero_grad(set_to_none=True) detaches them; None means zero)"""
+        if not self.with_grad:
+            return
+        for e in self.entries:
+            if not e.is_param:
+                continue
+            prm = e.module._parameters[e.attr]
+            if not prm.requires_grad:
+                continue
+            gv = self._view(self.grad, e)
+            if prm.grad is None or prm.grad.data_ptr() != gv.data_ptr():
+                if prm.grad is None:
+                    gv.zero_()
+                else:
+                    gv.copy_(prm.grad)
+                prm.grad = gv
+
+    # ------------------------------------------------------------------ access for kernels
+    def entry(self, t):
+        e = self.by_id.get(id(t))
+        if e is None:
+            raise S4FError('tensor is not managed by this ParamStore')
+        return e
+
+    def phys(self, t):
+        """fp32 physical (contiguous) view of a parameter/buffer"""
+        e = self.entry(t)
+        return self.flat[e.off:e.off + e.numel]
+
+    def grad_phys(self, t):
+        e = self.entry(t)
+        return self.grad[e.off:e.off + e.numel]
+
+    def shadow(self, t):
+        """operand-typed physical view (bf16 shadow arena in perf mode, the fp32 master in parity mode)"""
+        e = self.entry(t)
+        src = self.flat_t if self.flat_t is not None else self.flat
+        return src[e.off:e.off + e.numel]
+
+    # ------------------------------------------------------------------ shadow maintenance
+    def _version_sum(self):
+        return sum(self._tensor(e)._version for e in self.entries if e.is_param)
+
+    def mark_dirty(self):
+        self._shadow_dirty = True
+
+    def sync_shadow(self):
+        """refresh the bf16 shadow if anything but our own fused kernels touched the masters"""
+        if self.flat_t is None:
+            return
+        v = self._version_sum()
+        if self._shadow_dirty or v != self._versions:
+            K.cast(self.flat, self.flat_t, BF16)
+            self._shadow_dirty = False
+            self._versions = v
+
+    def node_done(self):
+        """called by every autograd node of this replica at the end of its backward (hook for the data-parallel
+        gradient reducer: when the last pending node has run, the gradient arena is final)"""
+        cb = getattr(self, 'on_node_done', None)
+        if cb is not None:
+            cb()
+
+    def zero_grad(self):
+        if self.grad is not None:
+            self.grad.zero_()
+
+    def named_entries(self):
+        return [(e.name, e) for e in self.entries]

@@ -1,0 +1,27 @@
+"""Process-wide numeric mode of the hot path.
+
+'bf16' (default, perf mode): bf16 MFMA operands / activations, fp32 accumulate, fp32 master weights, residual
+stream, statistics and losses.  'fp32' (parity mode): the same kernels instantiated on exact fp32 MFMA.
+Select with set_compute_dtype() or the environment variable S4F_DTYPE=bf16|fp32."""
+import os
+
+from ._lib import BF16, F32
+
+_NAMES = {'bf16': BF16, 'bfloat16': BF16, 'fp32': F32, 'f32': F32, 'float32': F32}
+_code = _NAMES.get(os.environ.get('S4F_DTYPE', 'bf16').lower(), BF16)
+
+
+def set_compute_dtype(name):
+    global _code
+    if name not in _NAMES:
+        raise ValueError(f'unknown compute dtype {name!r}; use one of {sorted(_NAMES)}')
+    _code = _NAMES[name]
+
+
+def compute_dtype():
+    """S4F_BF16 or S4F_F32 (the `dtype` argument of the C ABI)"""
+    return _code
+
+
+def compute_dtype_name():
+    return 'bf16' if _code == BF16 else 'fp32'

@@ -1,0 +1,304 @@
+"""VisionTransformer backbone with the reference's constructor, forward signature, return convention and
+state-dict keys (reference mmseg/models/backbones/vit.py:237-264,479-570 and models/utils/embed.py), running on
+the C-ABI HIP kernels (functional.PatchEmbedFn / LayerFn).
+
+The torch.nn modules instantiated here (Conv2d, LayerNorm, Linear, MultiheadAttention) are parameter CONTAINERS:
+they give the reference's parameter names and default initialisers; their own forward() is never called on the
+product path.
+"""
+import math
+import os
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import runtime
+from ._lib import S4FError
+from .base_module import BaseModule, ModuleList, constant_init, kaiming_init, trunc_normal_
+from .functional import LayerFn, PatchEmbedFn
+from .params import ParamStore
+from .registry import BACKBONES
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+class PatchEmbed(BaseModule):
+    """Image to patch embedding (reference models/utils/embed.py:83-204), Conv2d k = s = patch_size."""
+
+    def __init__(self, in_channels=3, embed_dims=768, conv_type='Conv2d', kernel_size=16, stride=None, padding='corner',
+                 dilation=1, bias=True, norm_cfg=None, input_size=None, init_cfg=None):
+        super().__init__(init_cfg=init_cfg)
+        self.embed_dims = embed_dims
+        if stride is None:
+            stride = kernel_size
+        kernel_size, stride = to_2tuple(kernel_size), to_2tuple(stride)
+        assert kernel_size == stride, 'only non-overlapping patches are on the hot path'
+        assert norm_cfg is None, 'patch_norm is not used by the SETR configs'
+        self.kernel_size = kernel_size
+        self.padding = padding
+        self.projection = nn.Conv2d(in_channels, embed_dims, kernel_size, stride, 0, dilation, bias=bias)
+        self.norm = None
+        self.init_input_size = to_2tuple(input_size) if input_size else None
+        if input_size:
+            self.init_out_size = (self.init_input_size[0] // stride[0], self.init_input_size[1] // stride[1])
+        else:
+            self.init_out_size = None
+
+    def pad(self, x):
+        """AdaptivePadding 'corner' (embed.py:58-80): zero-pad bottom/right to a multiple of the patch size."""
+        ph, pw = self.kernel_size
+        H, W = x.shape[-2:]
+        pad_h, pad_w = (ph - H % ph) % ph, (pw - W % pw) % pw
+        if pad_h or pad_w:
+            if self.padding == 'corner':
+                x = F.pad(x, [0, pad_w, 0, pad_h])
+            else:
+                x = F.pad(x, [pad_w // 2, pad_w - pad_w // 2, pad_h // 2, pad_h - pad_h // 2])
+        return x
+
+
+class _AttnContainer(BaseModule):
+    """mmcv MultiheadAttention wrapper: parameter path `attn.attn.*` (nn.MultiheadAttention container)."""
+
+    def __init__(self, embed_dims, num_heads, bias=True):
+        super().__init__()
+        self.embed_dims, self.num_heads = embed_dims, num_heads
+        self.attn = nn.MultiheadAttention(embed_dims, num_heads, 0.0, bias=bias)
+        self.self_attn = None       # Q7: the patched mmcv stored head-averaged weights here (visualisation only)
+
+
+class _FFNContainer(BaseModule):
+    """mmcv FFN: parameter paths `ffn.layers.0.0.*`, `ffn.layers.1.*`."""
+
+    def __init__(self, embed_dims, feedforward_channels):
+        super().__init__()
+        self.layers = nn.Sequential(
+            nn.Sequential(nn.Linear(embed_dims, feedforward_channels), nn.GELU(), nn.Dropout(0.0)),
+            nn.Linear(feedforward_channels, embed_dims), nn.Dropout(0.0))
+
+
+class TransformerEncoderLayer(BaseModule):
+    """reference vit.py:28-127.  forward(x, attn_mask) with attn_mask given in the rank-1 form
+    (bias_u [B,N], row_flag [B,N] | None, weight) or None."""
+
+    def __init__(self, embed_dims, num_heads, feedforward_channels, drop_rate=0., attn_drop_rate=0., drop_path_rate=0.,
+                 num_fcs=2, qkv_bias=True, act_cfg=dict(type='GELU'), norm_cfg=dict(type='LN'), batch_first=True,
+                 attn_cfg=dict(), ffn_cfg=dict(), with_cp=False):
+        super().__init__()
+        if drop_rate or attn_drop_rate or drop_path_rate:
+            raise S4FError('dropout / drop-path are 0 in every SETR config; the fused layer has no dropout')
+        assert num_fcs == 2 and act_cfg.get('type') == 'GELU' and norm_cfg.get('type') == 'LN'
+        assert embed_dims % num_heads == 0 and embed_dims // num_heads == 64, 'the attention kernels are built for head dim 64'
+        self.embed_dims, self.num_heads = embed_dims, num_heads
+        self.eps = float(norm_cfg.get('eps', 1e-5))
+        self.ln1 = nn.LayerNorm(embed_dims, eps=self.eps)
+        self.attn = _AttnContainer(embed_dims, num_heads, bias=qkv_bias)
+        self.ln2 = nn.LayerNorm(embed_dims, eps=self.eps)
+        self.ffn = _FFNContainer(embed_dims, feedforward_channels)
+        self._store = None
+
+    @property
+    def norm1(self):
+        return self.ln1
+
+    @property
+    def norm2(self):
+        return self.ln2
+
+    def _params(self):
+        a, f = self.attn.attn, self.ffn.layers
+        return (self.ln1.weight, self.ln1.bias, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
+                self.ln2.weight, self.ln2.bias, f[0][0].weight, f[0][0].bias, f[1].weight, f[1].bias)
+
+    def forward(self, x, attn_mask=None):
+        store = self._store
+        if store is None:
+            raise S4FError('TransformerEncoderLayer must be run through VisionTransformer (it owns the ParamStore)')
+        bu = rf = None
+        bw = 0.0
+        if attn_mask is not None:
+            bu, rf, bw = attn_mask
+        return LayerFn.apply(x, bu, rf, float(bw), self.num_heads, self.eps, store, *self._params())
+
+
+@BACKBONES.register_module()
+class VisionTransformer(BaseModule):
+    """reference vit.py:129-577 (DeiT-B / ViT for SETR)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_channels=3, embed_dims=768, num_layers=12, num_heads=12, mlp_ratio=4,
+                 out_indices=-1, qkv_bias=True, drop_rate=0., attn_drop_rate=0., drop_path_rate=0., with_cls_token=True,
+                 output_cls_token=False, norm_cfg=dict(type='LN'), act_cfg=dict(type='GELU'), patch_norm=False,
+                 final_norm=False, interpolate_mode='bicubic', num_fcs=2, norm_eval=False, with_cp=False, pretrained=None,
+                 init_cfg=None, no_pos_embed=False, feature_ps_indices=0, w_PatchRelativeAttention=False):
+        super().__init__(init_cfg=init_cfg)
+        if isinstance(img_size, int):
+            img_size = to_2tuple(img_size)
+        elif isinstance(img_size, tuple):
+            if len(img_size) == 1:
+                img_size = to_2tuple(img_size[0])
+            assert len(img_size) == 2, f'The size of image should have length 1 or 2, but got {len(img_size)}'
+        if output_cls_token:
+            assert with_cls_token is True, f'with_cls_token must be True if set output_cls_token to True, but got {with_cls_token}'
+        assert not (init_cfg and pretrained), 'init_cfg and pretrained cannot be set at the same time'
+        if isinstance(pretrained, str):
+            warnings.warn('DeprecationWarning: pretrained is deprecated, please use "init_cfg" instead')
+            self.init_cfg = dict(type='Pretrained', checkpoint=pretrained)
+        elif pretrained is not None:
+            raise TypeError('pretrained must be a str or None')
+        if patch_size != 16 or in_channels != 3:
+            raise S4FError('the patch-embed kernels are built for 16x16 RGB patches')
+        if not with_cls_token or patch_norm or w_PatchRelativeAttention or with_cp:
+            raise S4FError('with_cls_token=False / patch_norm / PatchRelativeAttention / with_cp are outside the SETR hot path')
+        self.img_size, self.patch_size = tuple(img_size), patch_size
+        self.interpolate_mode, self.norm_eval, self.with_cp = interpolate_mode, norm_eval, with_cp
+        self.pretrained, self.num_heads, self.embed_dims = pretrained, num_heads, embed_dims
+        self.no_pos_embed = no_pos_embed
+        self.w_PatchRelativeAttention = False
+
+        self.patch_embed = PatchEmbed(in_channels=in_channels, embed_dims=embed_dims, conv_type='Conv2d',
+                                      kernel_size=patch_size, stride=patch_size, padding='corner', norm_cfg=None)
+        num_patches = (img_size[0] // patch_size) * (img_size[1] // patch_size)
+        self.with_cls_token, self.output_cls_token = with_cls_token, output_cls_token
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dims))
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dims))
+        if drop_rate:
+            raise S4FError('drop_rate must be 0 on the fused path')
+        self.drop_after_pos = nn.Dropout(p=drop_rate)
+        if isinstance(out_indices, int):
+            if out_indices == -1:
+                out_indices = num_layers - 1
+            self.out_indices = [out_indices]
+        elif isinstance(out_indices, (list, tuple)):
+            self.out_indices = list(out_indices)
+        else:
+            raise TypeError('out_indices must be type of int, list or tuple')
+        self.layers = ModuleList([
+            TransformerEncoderLayer(embed_dims=embed_dims, num_heads=num_heads, feedforward_channels=mlp_ratio * embed_dims,
+                                    attn_drop_rate=attn_drop_rate, drop_rate=drop_rate, drop_path_rate=0., num_fcs=num_fcs,
+                                    qkv_bias=qkv_bias, act_cfg=act_cfg, norm_cfg=norm_cfg, with_cp=with_cp, batch_first=True)
+            for _ in range(num_layers)])
+        self.final_norm = final_norm
+        if final_norm:
+            raise S4FError('final_norm=True is not used by the SETR configs')
+        self.multi_self_attn = None
+        self._store = None          # set by the segmentor, or created lazily for a stand-alone backbone
+        self._store_owner = False
+
+    # ------------------------------------------------------------------ weights
+    def init_weights(self):
+        ck = self.init_cfg.get('checkpoint') if isinstance(self.init_cfg, dict) else None
+        if isinstance(self.init_cfg, dict) and self.init_cfg.get('type') == 'Pretrained' and ck and os.path.exists(ck):
+            checkpoint = torch.load(ck, map_location='cpu')
+            state_dict = checkpoint['state_dict'] if 'state_dict' in checkpoint else checkpoint
+            if 'pos_embed' in state_dict and self.pos_embed.shape != state_dict['pos_embed'].shape:
+                h, w = self.img_size
+                pos_size = int(math.sqrt(state_dict['pos_embed'].shape[1] - 1))
+                state_dict['pos_embed'] = self.resize_pos_embed(
+                    state_dict['pos_embed'], (h // self.patch_size, w // self.patch_size), (pos_size, pos_size),
+                    self.interpolate_mode, self.no_pos_embed)
+            self.load_state_dict(state_dict, strict=False)
+            return
+        if isinstance(self.init_cfg, dict) and self.init_cfg.get('type') == 'Pretrained':
+            warnings.warn(f'checkpoint {ck!r} not found: falling back to the random (jax_impl) initialisation')
+        # vit.py:396-414
+        trunc_normal_(self.pos_embed, std=.02)
+        trunc_normal_(self.cls_token, std=.02)
+        for n, m in self.named_modules():
+            if isinstance(m, nn.Linear):
+                trunc_normal_(m.weight, std=.02)
+                if m.bias is not None:
+                    if 'ffn' in n:
+                        nn.init.normal_(m.bias, mean=0., std=1e-6)
+                    else:
+                        nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Conv2d):
+                kaiming_init(m, mode='fan_in', bias=0.)
+            elif isinstance(m, (nn.modules.batchnorm._BatchNorm, nn.GroupNorm, nn.LayerNorm)):
+                constant_init(m, val=1.0, bias=0.)
+        if self._store is not None:
+            self._store.mark_dirty()
+
+    @staticmethod
+    def resize_pos_embed(pos_embed, input_shpae, pos_shape, mode, no_pos_embed=False):
+        """vit.py:447-477 (checkpoint-load / inference path; plain torch, not on the training hot path)."""
+        assert pos_embed.ndim == 3, 'shape of pos_embed must be [B, L, C]'
+        pos_h, pos_w = pos_shape
+        cls_token_weight = pos_embed[:, 0:1]
+        pos_embed_weight = pos_embed[:, (-1 * pos_h * pos_w):]
+        pos_embed_weight = pos_embed_weight.reshape(1, pos_h, pos_w, pos_embed.shape[2]).permute(0, 3, 1, 2)
+        pos_embed_weight = F.interpolate(pos_embed_weight, size=input_shpae, align_corners=False, mode=mode)
+        pos_embed_weight = torch.flatten(pos_embed_weight, 2).transpose(1, 2)
+        if no_pos_embed:
+            pos_embed_weight = torch.zeros_like(pos_embed_weight)
+        return torch.cat((cls_token_weight, pos_embed_weight), dim=1)
+
+    # ------------------------------------------------------------------ store plumbing
+    def _attach_store(self, store):
+        self._store = store
+        for layer in self.layers:
+            layer._store = store
+
+    def _ensure_store(self, device):
+        if self._store is None:
+            self._store_owner = True
+            self._attach_store(ParamStore([('backbone', self, '')], with_grad=True))
+        if self._store_owner:
+            self._store.ensure(device, runtime.compute_dtype())
+            self._store.ensure_grads()
+            self._store.sync_shadow()
+        return self._store
+
+    @staticmethod
+    def _rank1_mask(attn_mask, attn_mask_weight, adaptive_attn_mask):
+        """vit.py:519-535 in rank-1 form: bias[b,i,j] = weight * u_j * flag_i (never materialised)."""
+        B = attn_mask.size(0)
+        u = attn_mask.reshape(B, -1).to(torch.float32)
+        u = torch.cat((torch.zeros([B, 1], device=u.device), u), -1).contiguous()
+        flag = None
+        if adaptive_attn_mask:
+            # if the patch is more confident than half (<half), it is not encouraged to change
+            idx = torch.topk(u[:, 1:], int(0.5 * (u.size(-1) - 1)), dim=-1, largest=False)[1] + 1
+            flag = torch.ones_like(u)
+            flag[torch.arange(B, device=u.device).unsqueeze(1), idx] = 0
+        return u, flag, float(attn_mask_weight)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, inputs, no_pos_embed=False, avg_pos_emd=False, duplicate_pos_emd=False, use_fdrop=False,
+                attn_mask=None, attn_mask_weight=0.0, adaptive_attn_mask=False):
+        if no_pos_embed or avg_pos_emd or duplicate_pos_emd or use_fdrop:
+            raise S4FError('position-embedding ablations / fdrop are outside the hot path (SURVEY §8)')
+        if not inputs.is_cuda:
+            raise S4FError('VisionTransformer runs on the HIP kernels only: move the model and inputs to the GPU')
+        store = self._ensure_store(inputs.device)
+        x = self.patch_embed.pad(inputs.to(torch.float32)).contiguous()
+        B, _, H, W = x.shape
+        hw_shape = (H // self.patch_size, W // self.patch_size)
+        pe = self.patch_embed.projection
+        tokens = PatchEmbedFn.apply(x, pe.weight, pe.bias, self.cls_token, self.pos_embed, store)
+        mask = None
+        if attn_mask is not None and self.with_cls_token:
+            mask = self._rank1_mask(attn_mask, attn_mask_weight, adaptive_attn_mask)
+        outs = []
+        for i, layer in enumerate(self.layers):
+            tokens = layer(tokens, mask)
+            if i in self.out_indices:
+                C = tokens.shape[-1]
+                # [B, C, h, w] view of the patch tokens (vit.py:555-562 without the copy); the token tensor rides
+                # along so that the SETR head can read it token-major
+                out = tokens[:, 1:].reshape(B, hw_shape[0], hw_shape[1], C).permute(0, 3, 1, 2)
+                out._s4f_tokens = tokens
+                out._s4f_grid = hw_shape
+                if self.output_cls_token:
+                    out = [out, tokens[:, 0]]
+                outs.append(out)
+        self.multi_self_attn = [[], hw_shape]
+        return tuple(outs)
+
+    def train(self, mode=True):
+        super().train(mode)
+        return self

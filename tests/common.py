@@ -1,0 +1,122 @@
+"""Shared, repo-owned deterministic fixtures: model configs, weights and batches are generated from seeded CPU
+generators so that the build container (where the goldens are made from the reference's own code) and the GPU
+box (where /root/reference does not exist) see bit-identical tensors."""
+import copy
+import hashlib
+
+import numpy as np
+import torch
+
+NORM_BB = dict(type='LN', eps=1e-6, requires_grad=True)
+NORM_HEAD = dict(type='SyncBN', requires_grad=True)
+
+
+def tiny_model_cfg(img=64, embed=256, layers=4, heads=4, channels=128, num_classes=21, **flags):
+    """a scaled-down copy of configs/setr/*_MT.py:137-241 (same structure: 4 taps, PUP decode head with 4 convs
+    x2, four aux heads with 2 convs x4)"""
+    backbone = dict(type='VisionTransformer', img_size=(img, img), patch_size=16, in_channels=3, embed_dims=embed,
+                    num_layers=layers, num_heads=heads, out_indices=tuple(range(layers - 4, layers)), drop_rate=0.0,
+                    norm_cfg=NORM_BB, with_cls_token=True, interpolate_mode='bilinear')
+    decode = dict(type='SETRUPHead', in_channels=embed, channels=channels, in_index=3, num_classes=num_classes,
+                  dropout_ratio=0, norm_cfg=NORM_HEAD, num_convs=4, up_scale=2, kernel_size=3, align_corners=False,
+                  loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+    aux = [dict(type='SETRUPHead', in_channels=embed, channels=channels, in_index=i, num_classes=num_classes,
+                dropout_ratio=0, norm_cfg=NORM_HEAD, num_convs=2, up_scale=4, kernel_size=3, align_corners=False,
+                loss_decode=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=0.4)) for i in range(4)]
+    cfg = dict(type='EncoderDecoder', pretrained=None, backbone=backbone, backbone_ema=copy.deepcopy(backbone),
+               auxiliary_head=aux, decode_head=decode, decode_head_ema=copy.deepcopy(decode), ema=True, ema_momentum=0.999,
+               unsup_weight=1.0, unsup_confidence=0.95, test_cfg=dict(mode='whole'))
+    cfg.update(flags)
+    return cfg
+
+
+def deit_b_cfg(img=512, num_classes=21, **flags):
+    """the model dict of configs/setr/setr_deit-base_pup_..._MT.py:137-241 (values as resolved by the survey)"""
+    cfg = tiny_model_cfg(img=img, embed=768, layers=12, heads=12, channels=256, num_classes=num_classes, **flags)
+    for k in ('backbone', 'backbone_ema'):
+        cfg[k]['out_indices'] = (4, 7, 9, 11)
+    return cfg
+
+
+def fill_state(sd_keys_shapes, seed, teacher_seg_gain=1.0):
+    """deterministic values for every state-dict entry, by key order: weights ~ N(0, s) with a per-kind scale,
+    BN/LN weights near 1, running_var > 0.  Returns an OrderedDict of CPU fp32 tensors."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, shape in sd_keys_shapes:
+        leaf = k.split('.')[-1]
+        if leaf == 'num_batches_tracked':
+            out[k] = torch.zeros(shape, dtype=torch.long)
+            continue
+        t = torch.randn(shape, generator=g)
+        if leaf == 'running_var':
+            t = t.abs() * 0.2 + 0.8
+        elif leaf == 'running_mean':
+            t = t * 0.1
+        elif leaf in ('weight',) and len(shape) == 1:           # LN / BN gamma
+            t = 1.0 + 0.1 * t
+        elif leaf in ('bias', 'in_proj_bias') and len(shape) == 1:
+            t = 0.02 * t
+        elif 'conv_seg.weight' in k:
+            t = 0.05 * t * (teacher_seg_gain if k.startswith('decode_head_ema') else 1.0)
+        elif len(shape) == 4 and shape[-1] == 3:                 # 3x3 convs: kaiming fan_out
+            t = t * (2.0 / (shape[0] * 9)) ** 0.5
+        elif len(shape) == 4:                                    # patch embed
+            t = t * (2.0 / (shape[1] * shape[2] * shape[3])) ** 0.5
+        elif k.endswith('pos_embed') or k.endswith('cls_token'):
+            t = 0.02 * t
+        else:                                                    # linear weights
+            t = 0.04 * t
+        out[k] = t
+    return out
+
+
+def load_filled(model, seed, teacher_seg_gain=1.0):
+    sd = model.state_dict()
+    vals = fill_state([(k, tuple(v.shape)) for k, v in sd.items()], seed, teacher_seg_gain)
+    missing = model.load_state_dict(vals, strict=True)
+    return vals
+
+
+def make_batch(seed, n_sup, n_unsup, img=64, num_classes=21, block=8, border=2):
+    """SURVEY §8d synthetic inputs: img ~ N(0,1) clipped to [-2.2, 2.7]; labels = blocks of a uniform class with a
+    255 border band; student/teacher views = same crop + independent N(0, 0.1^2) noise; tags in the order
+    sup..., unsup_student..., unsup_teacher..., matching filenames."""
+    g = torch.Generator().manual_seed(seed)
+    n = n_sup + 2 * n_unsup
+    base = torch.randn(n_sup + n_unsup, 3, img, img, generator=g).clamp_(-2.2, 2.7)
+    imgs = [base[:n_sup]]
+    if n_unsup:
+        u = base[n_sup:]
+        imgs.append((u + 0.1 * torch.randn(u.shape, generator=g)).clamp_(-2.2, 2.7))
+        imgs.append((u + 0.1 * torch.randn(u.shape, generator=g)).clamp_(-2.2, 2.7))
+    imgs = torch.cat(imgs, 0).contiguous()
+    nb = img // block
+    cls = torch.randint(0, num_classes, (n, nb, nb), generator=g)
+    gt = cls.repeat_interleave(block, 1).repeat_interleave(block, 2)
+    band = torch.zeros(img, dtype=torch.bool)
+    for s in range(0, img, block * 4):
+        band[s:s + border] = True
+    gt[:, band, :] = 255
+    gt[:, :, band] = 255
+    gt = gt.unsqueeze(1).contiguous()
+    metas = []
+    for i in range(n_sup):
+        metas.append(dict(tag='sup', filename=f'sup_{i}.jpg'))
+    for i in range(n_unsup):
+        metas.append(dict(tag='unsup_student', filename=f'{i}.jpg'))
+    for i in range(n_unsup):
+        metas.append(dict(tag='unsup_teacher', filename=f'{i}.jpg'))
+    return imgs, gt, metas
+
+
+def sha(t):
+    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+
+
+def grad_norms(model, prefix_filter=None):
+    out = {}
+    for n, p in model.named_parameters():
+        if p.grad is not None and (prefix_filter is None or n.startswith(prefix_filter)):
+            out[n] = float(p.grad.detach().float().norm())
+    return out

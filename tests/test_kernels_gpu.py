@@ -143,11 +143,11 @@ def test_patch_embed(K, code):
     patches, hw = O.patch_embed(q(img, code), w, b)
     ref = O.assemble_tokens(patches, cls, pos)
     tpi = hw[0] * hw[1]
-    cols = torch.empty(B * tpi, 768, device='cuda', dtype=tdt(code))
-    K.im2col_patch16(dev(img), cols, code)
+    cols = torch.zeros(B * (tpi + 1), 768, device='cuda', dtype=tdt(code))
+    K.im2col_patch16(dev(img), cols, code, pad_cls=True)
     tokens = torch.zeros(B, tpi + 1, 768, device='cuda')
-    K.gemm(cols, dev(w.reshape(768, 768), code), B * tpi, 768, 768, 768, 768, code, bias=dev(b), out_f32=tokens,
-           ldo_f32=768, rowmap_tpi=tpi, pos=dev(pos.reshape(-1, 768)))
+    K.gemm(cols, dev(w.reshape(768, 768), code), B * (tpi + 1), 768, 768, 768, 768, code, bias=dev(b), out_f32=tokens,
+           ldo_f32=768, pos_period=tpi + 1, pos=dev(pos.reshape(-1, 768)))
     K.cls_pos(dev(cls.reshape(-1)), dev(pos.reshape(-1, 768)), tokens)
     check(tokens, ref, code, 'patch embed + token assembly')
     # backward of the assembly
@@ -156,6 +156,9 @@ def test_patch_embed(K, code):
     K.tokens_bwd(dev(dtok), dpos, dcls)
     check(dpos, dtok.sum(0), 0, 'dpos')
     check(dcls, dtok[:, 0].sum(0), 0, 'dcls')
+    dbias = torch.zeros(768, device='cuda')
+    K.colsum(dev(dtok), 768, B * (tpi + 1), 768, dbias, 0, skip_period=tpi + 1)
+    check(dbias, dtok[:, 1:].sum((0, 1)), 0, 'patch-embed bias grad (cls rows skipped)')
 
 
 @pytest.mark.parametrize('code', DTYPES)
@@ -191,15 +194,17 @@ def test_layernorm(K, code, skip):
     yk = torch.empty(rows, C, device='cuda', dtype=tdt(code))
     mean, rstd = torch.empty(rows, device='cuda'), torch.empty(rows, device='cuda')
     xd = dev(x)
-    K.layernorm_fwd(xd, dev(gamma), dev(beta), yk, mean, rstd, rows, C, code, 1e-6, rows_per_img=ntok - skip, skip=skip)
+    xv = xd[:, skip:]                       # strided view: pointer at token `skip`, batch stride ntok*C
+    K.layernorm_fwd(xv, dev(gamma), dev(beta), yk, mean, rstd, rows, C, code, 1e-6, rows_per_img=ntok - skip,
+                    in_batch_stride=ntok * C)
     check(yk, y, code, 'layernorm fwd', tol=1e-4 if code == 0 else 1e-2)
     check(mean, xin.detach().mean(-1), 0, 'ln mean')
     dres = rnd(B, ntok, C, seed=5)
     dx = torch.zeros(B, ntok, C, device='cuda')
     dx_t = torch.zeros(B, ntok, C, device='cuda', dtype=tdt(code))
     dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
-    K.layernorm_bwd(dev(dy, code), xd, mean, rstd, dev(gamma), dev(dres), dx, dx_t, dg, db, rows, C, code,
-                    rows_per_img=ntok - skip, skip=skip)
+    K.layernorm_bwd(dev(dy, code), xv, mean, rstd, dev(gamma), dev(dres)[:, skip:], dx[:, skip:], dx_t[:, skip:], dg, db,
+                    rows, C, code, rows_per_img=ntok - skip, in_batch_stride=ntok * C)
     ref_dx = (xin.grad.reshape(B, ntok - skip, C) + dres[:, skip:])
     check(dx[:, skip:], ref_dx, code, 'layernorm dx (+resid)', tol=1e-4 if code == 0 else 1e-2)
     check(dx_t[:, skip:], ref_dx, code, 'layernorm dx T copy', tol=1e-4 if code == 0 else 1e-2)
@@ -210,8 +215,8 @@ def test_layernorm(K, code, skip):
         # accumulate mode
         base = rnd(B, ntok, C, seed=6)
         dx2 = dev(base.clone())
-        K.layernorm_bwd(dev(dy, code), xd, mean, rstd, dev(gamma), None, dx2, None, dg, db, rows, C, code,
-                        rows_per_img=ntok - skip, skip=skip, accumulate=True)
+        K.layernorm_bwd(dev(dy, code), xv, mean, rstd, dev(gamma), None, dx2[:, skip:], None, dg, db, rows, C, code,
+                        rows_per_img=ntok - skip, in_batch_stride=ntok * C, accumulate=True)
         check(dx2[:, skip:], base[:, skip:] + xin.grad.reshape(B, ntok - skip, C), code, 'layernorm accumulate',
               tol=1e-4 if code == 0 else 1e-2)
 
@@ -357,7 +362,7 @@ def test_upsample_ce(K, s, C):
     check(ls * (0.4 / numel), loss.reshape(1), 0, 'upsample+CE loss', tol=2e-5)
     dlo = torch.full((B, h, w, ldc), 7.0, device='cuda')
     dlo_t = torch.full((B, h, w, ldc), 7.0, device='cuda', dtype=torch.bfloat16)
-    K.upce_bwd(lod, labd, 0.4 / numel, dlo, dlo_t, B, h, w, C, ldc, s, 1)
+    K.upce_bwd(lod, labd, 0.8 / numel, dlo, dlo_t, B, h, w, C, ldc, s, 1, gscale_dev=torch.full((1,), 0.5, device='cuda'))
     check(dlo[..., :C], to_nhwc(lor.grad), 0, 'upsample+CE dlogits', tol=1e-4)
     assert float(dlo[..., C:].abs().max()) == 0.0, 'padding columns must be zero'
     check(dlo_t[..., :C], to_nhwc(lor.grad), 1, 'upsample+CE dlogits bf16 copy', tol=1e-2)

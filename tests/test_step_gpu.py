@@ -1,0 +1,138 @@
+"""GPU parity tests of the whole training step (product path through the C ABI) against the golden vectors made
+from the reference's own code and against the CPU oracle, on the tiny fixtures.
+
+fp32 parity mode: losses within 1e-4 relative (north_star's tolerance), per-parameter gradient norms within 1e-3
+at iteration 0.  bf16 perf mode: losses within 2e-2, gradient norms within 8e-2."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import s4former_amd as S
+from oracle import model as OM
+from tests import common as C
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+OPT = dict(type='SGD', momentum=0.9, weight_decay=0.0, paramwise_cfg=dict(custom_keys={'head': dict(lr_mult=10.)}))
+
+
+def load_gold(name):
+    z = np.load(os.path.join(GOLD, f'step_{name}.npz'), allow_pickle=False)
+    return z, json.loads(str(z['meta']))
+
+
+def build_product(meta, dtype, extra=None):
+    S.set_compute_dtype(dtype)
+    flags = dict(meta['flags'])
+    flags.update(extra or {})
+    model = S.build_segmentor(C.tiny_model_cfg(**flags))
+    model.train()
+    C.load_filled(model, meta['seed_w'], meta['gain'])
+    model.cuda()
+    opt = S.build_optimizer(model, dict(OPT, lr=meta['lr']))
+    return model, opt, S.PolyLR(opt, 80001)
+
+
+def run_product(model, opt, sched, meta, iters=2):
+    rec = []
+    for it in range(iters):
+        imgs, gt, metas = C.make_batch(meta['seed_b'] + it, meta['n_sup'], meta['n_unsup'])
+        sched.step(it)
+        opt.zero_grad()
+        out = model.train_step(dict(img=imgs.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda()), opt, iter=it)
+        out['loss'].backward()
+        torch.cuda.synchronize()
+        gn = {n: float(p.grad.norm()) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+        rec.append(dict(log=out['log_vars'], gn=gn))
+        opt.step()
+    torch.cuda.synchronize()
+    return rec
+
+
+@pytest.mark.parametrize('name', ['sup', 'mt_literal', 'mt_pasa'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_step_vs_golden(name, dtype):
+    z, meta = load_gold(name)
+    model, opt, sched = build_product(meta, dtype)
+    rec = run_product(model, opt, sched, meta)
+    ltol = {'fp32': (1e-4, 1e-3), 'bf16': (2e-2, 4e-2)}[dtype]
+    gtol = {'fp32': (1e-3, 5e-3), 'bf16': (8e-2, 1.5e-1)}[dtype]
+    msgs = []
+    for it in range(2):
+        keys = [str(k) for k in z[f'it{it}_loss_keys']]
+        vals = z[f'it{it}_loss_vals']
+        got_keys = sorted(k for k in rec[it]['log'] if 'loss' in k and k != 'loss')
+        assert got_keys == sorted(k for k in keys if 'loss' in k), (got_keys, keys)
+        for k, v in zip(keys, vals):
+            if 'loss' in k:
+                e = abs(rec[it]['log'][k] - v) / abs(v)
+                if e > ltol[it]:
+                    msgs.append(f'it{it} {k}: {rec[it]["log"][k]:.6f} vs {v:.6f} (rel {e:.2e})')
+        e = abs(rec[it]['log']['loss'] - float(z[f'it{it}_loss'])) / abs(float(z[f'it{it}_loss']))
+        if e > ltol[it]:
+            msgs.append(f'it{it} total loss rel {e:.2e}')
+        worst = (0.0, None)
+        gk = [str(k) for k in z[f'it{it}_gn_keys']]
+        assert sorted(gk) == sorted(rec[it]['gn']), set(gk) ^ set(rec[it]['gn'])
+        for k, v in zip(gk, z[f'it{it}_gn_vals']):
+            e = abs(rec[it]['gn'][k] - v) / (abs(v) + 1e-12)
+            if e > worst[0]:
+                worst = (e, k)
+        if worst[0] > gtol[it]:
+            msgs.append(f'it{it} grad norm {worst[1]}: rel {worst[0]:.2e}')
+    # state after two optimiser steps (student and EMA teacher)
+    sd = model.state_dict()
+    wtol = 2e-4 if dtype == 'fp32' else 2e-2
+    for k, ref in zip(z['final_sha_keys'], z['final_abs_sum']):
+        got = float(sd[str(k)].double().abs().sum())
+        if abs(got - ref) > wtol * abs(ref) + 1e-9:
+            msgs.append(f'final |{k}|_1: {got:.6f} vs {ref:.6f}')
+    assert not msgs, '\n'.join(msgs[:20])
+
+
+@pytest.mark.parametrize('dtype', ['fp32'])
+def test_teacher_pseudo_labels_vs_golden(dtype):
+    z, meta = load_gold('mt_pasa')
+    model, opt, sched = build_product(meta, dtype)
+    run_product(model, opt, sched, meta)
+    imgs, gt, metas = C.make_batch(meta['seed_b'] + 1, meta['n_sup'], meta['n_unsup'])
+    n0 = meta['n_sup'] + meta['n_unsup']
+    with torch.no_grad():
+        model.set_eval(True)
+        info = model.extract_teacher_info_ema(imgs[n0:].cuda(), metas[n0:])
+        model.set_train(True)
+    lab = info['hard_seg_label'].cpu().numpy()
+    ref = z['teacher_label_final']
+    mism = float((lab != ref).mean())
+    # bit-exact on identical logits is tested at kernel level; here the logits come out of ~40 fp32 kernels whose
+    # summation order differs from ATen's, so isolated near-tie / near-threshold pixels may flip
+    assert mism < 2e-3, f'{mism:.4%} pseudo-label pixels differ'
+    mr = float(info['conf_count']) / lab.size
+    assert abs(mr - float(z['teacher_mask_ratio_final'])) < 2e-3
+
+
+def test_plain_mt_pseudo_loss_vs_oracle():
+    """extension flag (no reference counterpart): compute_pseudo_loss on the plain mean-teacher branch"""
+    z, meta = load_gold('mt_literal')
+    extra = dict(plain_mt_pseudo_loss=True)
+    model, opt, sched = build_product(meta, 'fp32', extra)
+    rec = run_product(model, opt, sched, meta, iters=1)
+    cfg = C.tiny_model_cfg(**dict(meta['flags'], **extra))
+    orc = OM.oracle_from_cfg(cfg)
+    orc.train()
+    orc.load_state_dict(C.fill_state([(k, tuple(v.shape)) for k, v in orc.state_dict().items()], meta['seed_w'], meta['gain']))
+    imgs, gt, metas = C.make_batch(meta['seed_b'], meta['n_sup'], meta['n_unsup'])
+    losses = orc.forward_train(imgs, [m['tag'] for m in metas], gt)
+    loss, _ = orc.parse_losses(losses)
+    loss.backward()
+    assert sorted(k for k in losses if 'loss' in k) == sorted(k for k in rec[0]['log'] if 'loss' in k and k != 'loss')
+    for k, v in losses.items():
+        assert abs(rec[0]['log'][k] - float(v)) <= 1e-4 * abs(float(v)), (k, rec[0]['log'][k], float(v))
+    for n, p in orc.named_parameters():
+        if p.grad is not None:
+            r = float(p.grad.norm())
+            assert abs(rec[0]['gn'][n] - r) <= 2e-3 * r + 1e-9, (n, rec[0]['gn'][n], r)
+    assert abs(float(model.last_mask_ratio) - float(orc.last['mask_ratio'])) < 2e-3
