@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""Benchmark of the S4Former training step (DeiT-B / SETR-PUP, 512x512, synthetic data, random-init weights).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+      bench.py --gpus N --steps K --warmup W
+
+A step = zero_grad, forward_train (EMA update, supervised branch, teacher pseudo-labels, pseudo-label CE),
+backward, gradient all-reduce (N > 1), fused SGD.  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line (metric / roofline / cpu_baseline as specified by the build contract).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}      # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
+
+WORKLOADS = {
+    # name: (n_sup, n_unsup, img, classes, model flags, description)
+    'sup': (8, 0, 512, 21, dict(unsup_weight=0), 'cfg2: SETR DeiT-B PUP supervised-only bs=8 512x512 (EMA on, unsup_weight=0)'),
+    'semi': (8, 8, 512, 21, dict(unsup_weight=1.0, plain_mt_pseudo_loss=True),
+             'cfg3/4: S4Former mean-teacher semi 8+8 512x512 th=0.95, pseudo-label CE enabled'),
+    'semi768': (4, 4, 768, 19, dict(unsup_weight=1.0, plain_mt_pseudo_loss=True),
+                'cfg5: S4Former Cityscapes 768x768 4+4, pseudo-label CE enabled'),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='semi', choices=sorted(WORKLOADS))
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--mask-ratio', type=float, default=0.5,
+                    help='target fraction of confident teacher pixels: the randomly initialised teacher conv_seg is '
+                         'rescaled (bisection, untimed) so that the pseudo-label path is not degenerate (SURVEY §7)')
+    return ap.parse_args()
+
+
+def cpu_baseline():
+    """the oracle (CPU restatement of the reference step) timed on this box's host cores: cfg1 = DeiT-B PUP
+    supervised-only semantics (EMA on), bs 2, 512x512, SGD momentum; 1 warm-up + 1 timed step."""
+    from oracle import model as OM
+    from s4former_amd.presets import setr_pup_model, synthetic_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    cfg = setr_pup_model(unsup_weight=0)
+    orc = OM.oracle_from_cfg(cfg)
+    orc.train()
+    opt = OM.build_optimizer(orc, 0.001)
+    imgs, gt, metas = synthetic_batch(1999, 2, 0)
+    tags = [m['tag'] for m in metas]
+    times = []
+    for it in range(2):
+        t0 = time.time()
+        OM.set_poly_lr(opt, it)
+        opt.zero_grad()
+        loss, _ = orc.parse_losses(orc.forward_train(imgs, tags, gt))
+        loss.backward()
+        opt.step()
+        times.append(time.time() - t0)
+    return dict(value=round(2.0 / times[-1], 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample='cfg1: DeiT-B PUP sup-only (EMA on) bs=2 512x512 fp32, oracle (torch CPU restatement of the '
+                       'reference step), 1 warm-up + 1 timed step', seconds_per_step=round(times[-1], 2),
+                torch=torch.__version__)
+
+
+def calibrate_teacher(model, batch, n_sup, n_unsup, target):
+    """rescale decode_head_ema.conv_seg (weights are random: max-softmax ~ 1/C, nothing would pass th=0.95) so that
+    about `target` of the teacher pixels are confident. Deterministic (same seeds on every rank), untimed."""
+    imgs, gt, metas = batch
+    timg = imgs[n_sup + n_unsup:]
+    w = model.decode_head_ema.conv_seg.weight
+    base = w.detach().clone()
+    lo, hi, gain = 1.0, 1e5, 1.0
+    for _ in range(18):
+        gain = (lo * hi) ** 0.5
+        with torch.no_grad():
+            w.copy_(base * gain)
+            model.teacher_store.mark_dirty()
+            model.ensure_engine(imgs.device)
+            model.set_eval(True)
+            info = model.extract_teacher_info_ema(timg, metas[n_sup + n_unsup:])
+            model.set_train(True)
+        r = float(info['conf_count']) / info['hard_seg_label'].numel()
+        if r < target:
+            lo = gain
+        else:
+            hi = gain
+        if abs(r - target) < 0.03:
+            break
+    return gain
+
+
+def main():
+    args = parse()
+    import s4former_amd as S
+    from s4former_amd import _lib
+    from s4former_amd.dist import GradReducer, init_distributed
+    from s4former_amd.presets import MAX_ITERS, OPTIMIZER, setr_pup_model, step_gflop, synthetic_batch
+
+    rank, local, world = init_distributed()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback on the product path)'
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    S.set_compute_dtype(args.dtype)
+
+    n_sup, n_unsup, img, ncls, flags, desc = WORKLOADS[args.workload]
+    torch.manual_seed(1999)                       # identical random-init weights on every rank
+    model = S.build_segmentor(setr_pup_model(img=img, num_classes=ncls, **flags))
+    model.init_weights()
+    model.train()
+    model.to(dev)
+    model.log_vars_as_tensors = True              # no host sync inside the step
+    opt = S.build_optimizer(model, dict(OPTIMIZER))
+    sched = S.PolyLR(opt, MAX_ITERS)
+    reducer = GradReducer()
+
+    batches = [synthetic_batch(1999 + 17 * rank + i, n_sup, n_unsup, img=img, num_classes=ncls, device=dev) for i in range(2)]
+    model.ensure_engine(dev)
+    reducer.broadcast_(model.student_store.flat)
+    if model.teacher_store is not None:
+        reducer.broadcast_(model.teacher_store.flat)
+    model.student_store.mark_dirty()
+
+    seg_gain = 1.0
+    if n_unsup and rank == 0 or (n_unsup and world > 1):
+        seg_gain = calibrate_teacher(model, batches[0], n_sup, n_unsup, args.mask_ratio)
+
+    def step(it):
+        imgs, gt, metas = batches[it % 2]
+        sched.step(it)
+        opt.zero_grad()
+        out = model.train_step(dict(img=imgs, img_metas=metas, gt_semantic_seg=gt), opt, iter=it)
+        out['loss'].backward()
+        reducer.reduce_(model.student_store.grad)
+        reducer.wait()
+        opt.step(grad_scale=reducer.grad_scale())
+        return out
+
+    it = 0
+    for _ in range(args.warmup):
+        out = step(it)
+        it += 1
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(it)
+        it += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    losses = {k: float(v) for k, v in out['log_vars'].items()}
+    mask_ratio = float(model.last_mask_ratio) if model.last_mask_ratio is not None else None
+
+    ips = world * (n_sup + n_unsup) * args.steps / dt
+    gflop_step = step_gflop(n_sup, n_unsup, img=img, num_classes=ncls, pseudo_loss=True)
+    step_tflops = gflop_step * args.steps / dt / 1e3          # per GPU
+
+    # ---- live per-kernel durations (HIP events on the launch stream) for the dominant kernel
+    roofline = None
+    kprof = None
+    if rank == 0 and not args.no_kernel_profile:
+        with _lib.CallProfiler() as prof:
+            step(it)
+            it += 1
+        summ = prof.summary()
+        fam = {}
+        for (name, tag), d in summ.items():
+            key = name if name != 's4f_gemm' else f's4f_gemm[a{tag[0]},b{tag[1]}]'
+            f = fam.setdefault(key, dict(calls=0, ms=0.0, gflop=0.0))
+            f['calls'] += d['calls']
+            f['ms'] += d['ms']
+            if name == 's4f_gemm':
+                f['gflop'] += d['calls'] * 2.0 * tag[2] * tag[3] * tag[4] / 1e9
+        total_ms = sum(f['ms'] for f in fam.values())
+        kprof = {k: dict(calls=v['calls'], ms=round(v['ms'], 3), tflops=round(v['gflop'] / v['ms'], 1) if v['gflop'] else None)
+                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])}
+        gemm_ms = sum(v['ms'] for k, v in fam.items() if k.startswith('s4f_gemm'))
+        gemm_gflop = sum(v['gflop'] for k, v in fam.items() if k.startswith('s4f_gemm'))
+        gemm_calls = sum(v['calls'] for k, v in fam.items() if k.startswith('s4f_gemm'))
+        peak = MFMA_PEAK_TFLOPS[args.dtype]
+        roofline = dict(bound='mfma', kernel='gemm_kernel<T, AMODE, BMODE> (dense + implicit-GEMM conv family)',
+                        achieved=round(gemm_gflop / gemm_ms, 1), peak=peak, unit='TFLOP/s',
+                        frac=round(gemm_gflop / gemm_ms / peak, 4), traffic=None,
+                        launches_per_step=gemm_calls, avg_launch_ms=round(gemm_ms / gemm_calls, 4),
+                        share_of_step_kernel_time=round(gemm_ms / total_ms, 3),
+                        step=dict(achieved=round(step_tflops, 1), frac=round(step_tflops / peak, 4),
+                                  gflop_per_step_per_gpu=round(gflop_step, 1)))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = dict(metric='train images/sec DeiT-B 512x512 S4Former step', value=round(ips, 3), unit='images/s',
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
+                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
+                    config=dict(workload=f'{args.workload}: {desc}', images_per_step_per_gpu=n_sup + n_unsup,
+                                crop=f'{img}x{img}', classes=ncls, parallelism=f'dp{world}', weights='random-init DeiT-B',
+                                teacher_conv_seg_gain=round(seg_gain, 2)),
+                    roofline=roofline, cpu_baseline=cpu, losses=losses, mask_ratio=mask_ratio)
+        if kprof is not None:
+            os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+            with open(os.path.join(ROOT, 'gpurun_out', f'bench_kernels_{args.workload}_{args.dtype}.json'), 'w') as f:
+                json.dump(kprof, f, indent=1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -102,9 +102,48 @@ def load():
     return lib
 
 
-def call(name, *args):
+_prof = None
+
+
+class CallProfiler:
+    """Times every C-ABI launch with HIP events recorded on the launch stream (markers only: nothing is
+    serialised).  Used by bench.py for the live per-kernel durations behind the `roofline` object."""
+
+    def __init__(self):
+        self.entries = []
+
+    def __enter__(self):
+        global _prof
+        self._prev, _prof = _prof, self
+        return self
+
+    def __exit__(self, *exc):
+        global _prof
+        _prof = self._prev
+        return False
+
+    def summary(self):
+        """{(name, tag): dict(calls, ms)} after a device synchronise"""
+        torch.cuda.synchronize()
+        out = {}
+        for name, tag, e0, e1 in self.entries:
+            d = out.setdefault((name, tag), dict(calls=0, ms=0.0))
+            d['calls'] += 1
+            d['ms'] += e0.elapsed_time(e1)
+        return out
+
+
+def call(name, *args, tag=None):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if _prof is not None:
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        _prof.entries.append((name, tag, e0, e1))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise S4FError(f'{name} failed ({rc}): {lib.s4f_last_error().decode(errors="replace")}')
 

@@ -104,7 +104,7 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
     d.aux, d.ld_aux = p(aux), ld_aux
     d.act, d.atomic = act, 1 if atomic else 0
     d.pos_period, d.pos = pos_period, p(pos)
-    call('s4f_gemm', ctypes.byref(d), stream())
+    call('s4f_gemm', ctypes.byref(d), stream(), tag=(a_mode, b_mode, M, N, K))
 
 
 def cast(src, dst, dtype):
