@@ -49,12 +49,24 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores():
+    """host cores this process may really use: affinity mask capped by the cgroup CPU quota"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline():
     """the oracle (CPU restatement of the reference step) timed on this box's host cores: cfg1 = DeiT-B PUP
     supervised-only semantics (EMA on), bs 2, 512x512, SGD momentum; 1 warm-up + 1 timed step."""
     from oracle import model as OM
     from s4former_amd.presets import setr_pup_model, synthetic_batch
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     cfg = setr_pup_model(unsup_weight=0)
