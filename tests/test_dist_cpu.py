@@ -1,0 +1,87 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: bucketed gradient all-reduce + 1/world scaling, batched log-scalar
+reduction of _parse_losses, SyncBN statistics = statistics of the concatenated global batch, identical replicas."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from s4former_amd.dist import GradReducer, init_distributed, world_size
+    from s4former_amd.encoder_decoder import BaseSegmentor
+    r, l, w = init_distributed(backend='gloo')
+    assert (r, w) == (rank, world) and world_size() == world
+    res = {}
+    # 1. gradient arena: bucketed sum all-reduce, mean via grad_scale
+    g = torch.Generator().manual_seed(100 + rank)
+    grad = torch.randn(300_001, generator=g)
+    red = GradReducer(bucket_mb=0.25, side_stream=False)      # 65536-element buckets -> 5 buckets
+    red.reduce_(grad)
+    red.wait()
+    res['grad'] = (grad * red.grad_scale()).clone()
+    # 2. parameters broadcast from rank 0
+    p = torch.full((1000,), float(rank))
+    red.broadcast_(p, src=0)
+    res['bcast'] = float(p.abs().max())
+    # 3. batched log-scalar reduction
+    seg = BaseSegmentor()
+    losses = {'decode.loss_ce': torch.tensor(1.0 + rank), 'aux_0.loss_ce': torch.tensor(0.5 * (rank + 1)), 'mask_ratio': torch.tensor(0.25 * rank)}
+    loss, log_vars = seg._parse_losses(losses)
+    res['loss_local'] = float(loss)
+    res['log_vars'] = dict(log_vars)
+    # 4. SyncBN statistics: all-reduced (sum, sumsq) == statistics of the concatenated batch
+    gx = torch.Generator().manual_seed(7 + rank)
+    x = torch.randn(64, 8, generator=gx) * (1 + rank) + rank
+    sums = torch.cat([x.sum(0), (x * x).sum(0)])
+    dist.all_reduce(sums)
+    n = 64 * world
+    mean = sums[:8] / n
+    var = sums[8:] / n - mean * mean
+    res['bn'] = (mean, var, x)
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    out = {}
+    for _ in range(world):
+        r, res = q.get(timeout=120)
+        out[r] = res
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    g0 = torch.randn(300_001, generator=torch.Generator().manual_seed(100))
+    g1 = torch.randn(300_001, generator=torch.Generator().manual_seed(101))
+    ref = (g0 + g1) / 2
+    assert torch.allclose(out[0]['grad'], ref, atol=1e-6) and torch.equal(out[0]['grad'], out[1]['grad'])
+    assert out[0]['bcast'] == 0.0 and out[1]['bcast'] == 0.0
+    # local loss stays local (it is what backward runs on); logged values are the rank mean
+    assert out[0]['loss_local'] == 1.5 and out[1]['loss_local'] == 3.0
+    for r in range(2):
+        lv = out[r]['log_vars']
+        assert abs(lv['decode.loss_ce'] - 1.5) < 1e-6 and abs(lv['aux_0.loss_ce'] - 0.75) < 1e-6
+        assert abs(lv['mask_ratio'] - 0.125) < 1e-6 and abs(lv['loss'] - 2.25) < 1e-6
+    xc = torch.cat([out[0]['bn'][2], out[1]['bn'][2]])
+    assert torch.allclose(out[0]['bn'][0], xc.mean(0), atol=1e-5)
+    assert torch.allclose(out[0]['bn'][1], xc.var(0, unbiased=False), atol=1e-4)
+    assert torch.equal(out[0]['bn'][0], out[1]['bn'][0])
