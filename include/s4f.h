@@ -78,6 +78,9 @@ typedef struct s4f_gemm_desc {
   /* position-embedding add (patch embed): v += pos[(m % pos_period), n] */
   int32_t pos_period;
   const float* pos;         /* fp32 [pos_period, N] or NULL */
+  /* kernel selection: 0 = automatic; 1 = 128x128 register-staged kernel; 2 = 256x128 LDS-DMA kernel;
+   * 3 = 256x256 LDS-DMA kernel (2 and 3: bf16 only) */
+  int32_t tile_hint;
 } s4f_gemm_desc;
 
 int s4f_gemm(const s4f_gemm_desc* d, s4f_stream stream);

@@ -38,6 +38,7 @@ class GemmDesc(Structure):
         ('aux', c_void_p), ('ld_aux', c_int64),
         ('act', c_int32), ('atomic', c_int32),
         ('pos_period', c_int32), ('pos', c_void_p),
+        ('tile_hint', c_int32),
     ]
 
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -147,5 +148,16 @@ __device__ __forceinline__ float gelu_grad_f(float z) {
   const float pdf = 0.39894228040143267794f * expf(-0.5f * z * z);
   return cdf + z * pdf;
 }
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(<N-1>) — keeps register arrays statically indexed
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for_impl(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_impl<I + 1, N>(f);
+  }
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F f) { static_for_impl<0, N>(f); }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

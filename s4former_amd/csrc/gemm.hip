@@ -320,6 +320,23 @@ int dispatch(const s4f_gemm_desc& d, hipStream_t st) {
 
 }  // namespace
 
+int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn);   // gemm2.hip
+
+// 0 -> 128x128 kernel, 128 / 256 -> BN of the 256-row LDS-DMA kernel
+static int pick_tile(const s4f_gemm_desc& d) {
+  if (d.dtype != S4F_BF16) return 0;
+  if (d.tile_hint == 1) return 0;
+  if (d.tile_hint == 2) return 128;
+  if (d.tile_hint == 3) return 256;
+  const long sk = d.splitk < 1 ? 1 : d.splitk;
+  const long t256 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 256) * sk;
+  const long t128 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 128) * sk;
+  const bool n256ok = (d.N % 256 == 0) && (d.b_mode != S4F_OP_K_CONV || d.cC % 256 == 0);
+  if (n256ok && t256 >= 384) return 256;          // >= 1.5 blocks per CU of the big tile
+  if (t128 >= 160) return 128;
+  return 0;
+}
+
 S4F_API int s4f_gemm(const s4f_gemm_desc* dp, s4f_stream stream) {
   S4F_CHECK(dp != nullptr, "s4f_gemm: null descriptor");
   const s4f_gemm_desc& d = *dp;
@@ -354,7 +371,10 @@ S4F_API int s4f_gemm(const s4f_gemm_desc* dp, s4f_stream stream) {
     S4F_CHECK((long)d.cB * d.cH * d.cW == d.K, "s4f_gemm: wgrad K must be cB*cH*cW");
     S4F_CHECK(d.csign == 1, "s4f_gemm: wgrad csign must be +1");
   }
-  int rc = d.dtype == S4F_BF16 ? dispatch<bf16_t>(d, (hipStream_t)stream) : dispatch<float>(d, (hipStream_t)stream);
+  const int bn = pick_tile(d);
+  int rc = -100;
+  if (bn) rc = s4f_gemm2_try(d, (hipStream_t)stream, bn);
+  if (rc == -100) rc = d.dtype == S4F_BF16 ? dispatch<bf16_t>(d, (hipStream_t)stream) : dispatch<float>(d, (hipStream_t)stream);
   if (rc == -100) S4F_FAIL(-2, "s4f_gemm: unsupported operand mode pair (%d, %d)", d.a_mode, d.b_mode);
   S4F_LAUNCH_CHECK();
   return rc;

@@ -1,0 +1,363 @@
+// Fast bf16 path of the GEMM family (same operand modes and epilogues as gemm.hip): 256 x BN block tile
+// (BN = 128 | 256), 8 waves (4 x 2), wave tile 64 x BN/2, K step 64, operands streamed global -> LDS by
+// global_load_lds_dwordx4 (LDS-DMA, no staging registers) into a 2-deep LDS ring, one barrier per K step
+// (guide §5 "glds, 2 LDS buffers, BK=64, vmcnt(0) + plain __syncthreads()").
+//
+// LDS images (the DMA writes 1 KiB per wave-instruction, lane-linear, so every swizzle is applied to the SOURCE
+// address and undone on the read — guide rule 21):
+//   row-major operand  [rows][128 B]: 16-B chunk c of row r sits at chunk c ^ (r & 7)
+//   k-major operand    [64 k][cols] : one DMA = R = 1024 / rowbytes rows (2 for 256 columns, 4 for 128);
+//       groups are spaced 1024 + PAD bytes apart and chunk c of row r (in group) sits at c ^ (2 r), so that the
+//       8 k-rows one half-wave touches in a ds_read_b64_tr_b16 fall in 8 distinct 32-B bank slots.
+// Rows / chunks outside the problem (M, N, K edges, conv zero padding) are fetched from a zero page.
+#include "common.h"
+#include "../../include/s4f.h"
+
+namespace g2 {
+
+__device__ __attribute__((aligned(64))) char g_zero_page[64];
+
+struct GemmArgs {
+  s4f_gemm_desc d;
+  int nk;
+  int nk_per_split;
+  int tiles_m, tiles_n;
+};
+
+constexpr int BM = 256, BK = 64;
+
+template <int COLS> struct KImg {                 // k-major image geometry for COLS columns of bf16
+  static constexpr int RB = COLS * 2;             // row bytes: 512 / 256
+  static constexpr int R = 1024 / RB;             // rows per DMA: 2 / 4
+  static constexpr int PAD = (R == 2) ? 64 : 128;
+  static constexpr int GS = 1024 + PAD;           // group stride
+  static constexpr int NG = 64 / R;               // groups per tile: 32 / 16
+  static constexpr int BYTES = NG * GS;
+};
+template <int ROWS> struct RImg {
+  static constexpr int NG = ROWS / 8;             // DMAs per tile (8 rows of 128 B each)
+  static constexpr int BYTES = ROWS * 128;
+};
+
+__device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------- operand feeders
+// One feeder per operand: NSLOT DMA slots per thread per k-iteration.  All per-slot address arithmetic is
+// incremental: a slot keeps a byte pointer that advances by a constant per k-iteration; the conv modes
+// recompute it only when the tap changes (a wave-uniform branch every cC/64 iterations).
+template <int MODE, bool IS_A, int EXT>   // EXT = rows (row-major) or columns (k-major) of the tile
+struct Feeder {
+  static constexpr bool KM = (MODE == S4F_OP_K || MODE == S4F_OP_K_TAPSPLIT || MODE == S4F_OP_K_CONV);
+  static constexpr int NG = KM ? KImg<EXT>::NG : RImg<EXT>::NG;
+  static constexpr int NSLOT = NG / 8;
+  static constexpr int BYTES = KM ? KImg<EXT>::BYTES : RImg<EXT>::BYTES;
+  static constexpr int GSTRIDE = KM ? KImg<EXT>::GS : 1024;
+
+  const char* base;
+  long ld;
+  int idx0, lim, K;
+  int cH, cW, cC, csign;
+  const char* cur[NSLOT];     // source pointer of the slot for the current k-iteration (valid or not)
+  long step;                  // bytes per k-iteration
+  int kend[NSLOT];            // first k-iteration at which the slot falls off the K edge (0: never valid)
+  bool ok[NSLOT];             // conv: current tap position inside the image
+  int py[NSLOT], px[NSLOT], pb[NSLOT];
+  int srcchunk[NSLOT], krow[NSLOT];
+  int wave, lane;
+
+  // (re)compute the slot pointers for k-iteration kt (full recompute; used at start and on tap changes)
+  __device__ __forceinline__ void seek(int kt) {
+    const int k0 = kt * BK;
+#pragma unroll
+    for (int u = 0; u < NSLOT; ++u) {
+      if constexpr (MODE == S4F_OP_ROW_CONV) {
+        const int tap = k0 / cC;
+        const int c = k0 - tap * cC + srcchunk[u] * 8;
+        const int ty = tap / 3, tx = tap - 3 * ty;
+        const int yy = py[u] + csign * (ty - 1), xx = px[u] + csign * (tx - 1);
+        ok[u] = yy >= 0 && yy < cH && xx >= 0 && xx < cW;
+        cur[u] = base + ((((long)pb[u] * cH + yy) * cW + xx) * ld + c) * 2;
+      } else if constexpr (MODE == S4F_OP_K_TAPSPLIT) {
+        const int k = k0 + krow[u];
+        const int tap = k / cC;
+        const int co = k - tap * cC;
+        cur[u] = base + ((long)co * ld + (long)tap * lim + idx0 + srcchunk[u] * 8) * 2;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void init(const s4f_gemm_desc& d, int blk0, int kt0) {
+    wave = threadIdx.x >> 6; lane = threadIdx.x & 63;
+    base = reinterpret_cast<const char*>(IS_A ? d.A : d.B);
+    ld = IS_A ? d.lda : d.ldb;
+    idx0 = blk0; lim = IS_A ? d.M : d.N; K = d.K;
+    cH = d.cH; cW = d.cW; cC = d.cC; csign = d.csign;
+    const int k0 = kt0 * BK;
+#pragma unroll
+    for (int u = 0; u < NSLOT; ++u) {
+      const int t = wave + 8 * u;
+      ok[u] = true;
+      if constexpr (!KM) {
+        const int row = 8 * t + (lane >> 3);
+        srcchunk[u] = (lane & 7) ^ (row & 7);
+        const int gi = idx0 + row;
+        const int kc = srcchunk[u] * 8;
+        kend[u] = (gi < lim && kc < K) ? (K - kc + BK - 1) / BK : 0;
+        step = BK * 2;
+        if constexpr (MODE == S4F_OP_ROW) {
+          cur[u] = base + ((long)gi * ld + k0 + kc) * 2;
+        } else {
+          const int x = gi % cW;
+          const int tt = gi / cW;
+          px[u] = x; py[u] = tt % cH; pb[u] = tt / cH;
+        }
+      } else {
+        using G = KImg<EXT>;
+        const int r = (lane * 16) / G::RB;
+        const int cprime = ((lane * 16) % G::RB) / 16;
+        srcchunk[u] = cprime ^ (2 * r);
+        krow[u] = G::R * t + r;
+        const int col = idx0 + srcchunk[u] * 8;
+        kend[u] = (col < lim && krow[u] < K) ? (K - krow[u] + BK - 1) / BK : 0;
+        step = (long)BK * ld * 2;
+        if constexpr (MODE == S4F_OP_K) {
+          cur[u] = base + ((long)(k0 + krow[u]) * ld + col) * 2;
+        } else if constexpr (MODE == S4F_OP_K_CONV) {
+          const int k = k0 + krow[u];
+          px[u] = k % cW;
+          const int tt = k / cW;
+          py[u] = tt % cH; pb[u] = tt / cH;
+        }
+      }
+    }
+    seek(kt0);
+  }
+
+  __device__ __forceinline__ void issue(int kt, char* img) {
+    if constexpr (MODE == S4F_OP_ROW_CONV || MODE == S4F_OP_K_TAPSPLIT) {
+      if ((kt * BK) % cC == 0) seek(kt);             // wave-uniform: tap changed
+    }
+#pragma unroll
+    for (int u = 0; u < NSLOT; ++u) {
+      const int t = wave + 8 * u;
+      char* dst = img + t * GSTRIDE;
+      const char* src;
+      if constexpr (MODE == S4F_OP_K_CONV) {
+        // k = pixel index (advances by BK per iteration), column = tap * cC + c with the tap fixed per block
+        const int tap = idx0 / cC;
+        const int c = idx0 + srcchunk[u] * 8 - tap * cC;
+        const int ty = tap / 3, tx = tap - 3 * ty;
+        const int yy = py[u] + (ty - 1), xx = px[u] + (tx - 1);
+        const bool v = kt < kend[u] && yy >= 0 && yy < cH && xx >= 0 && xx < cW;
+        src = v ? base + ((((long)pb[u] * cH + yy) * cW + xx) * ld + c) * 2 : g_zero_page;
+        px[u] += BK;
+        while (px[u] >= cW) { px[u] -= cW; ++py[u]; }
+        while (py[u] >= cH) { py[u] -= cH; ++pb[u]; }
+      } else {
+        src = (kt < kend[u] && ok[u]) ? cur[u] : g_zero_page;
+        cur[u] += step;
+      }
+      glds16(src, dst);
+    }
+  }
+};
+
+// fragment reads ---------------------------------------------------------------------------------
+template <bool TRMAP>
+__device__ __forceinline__ void frag_row(Frag<bf16_t>& f, const char* img, int rc0, int s) {
+  const int l = threadIdx.x & 63, g = l >> 4, li = l & 15;
+  const int row = rc0 + li;
+  const char* rp = img + row * 128;
+  const int sw = row & 7;
+  if constexpr (!TRMAP) {
+    lds_read_lin(f, rp + (((s * 4 + g) ^ sw) << 4));
+  } else {
+    const int h0 = s * 8 + g, h1 = s * 8 + 4 + g;
+    lds_read_2x4(f, rp + (((h0 >> 1) ^ sw) << 4) + (h0 & 1) * 8, rp + (((h1 >> 1) ^ sw) << 4) + (h1 & 1) * 8);
+  }
+}
+template <int COLS>
+__device__ __forceinline__ void frag_k(Frag<bf16_t>& f, const char* img, int col0, int s) {
+  using G = KImg<COLS>;
+  const int l = threadIdx.x & 63, g = l >> 4, li = l & 15, q = li >> 2, p = li & 3;
+  const int chunk = (col0 >> 3) + (p >> 1);
+  s16x4 r[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int row = s * 32 + 16 * u + 4 * g + q;
+    const int j = row / G::R, rr = row % G::R;
+    const char* a = img + j * G::GS + rr * G::RB + ((chunk ^ (2 * rr)) << 4) + (p & 1) * 8;
+    r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  }
+  union { s16x4 s2[2]; bf16x8 b; } cv;
+  cv.s2[0] = r[0]; cv.s2[1] = r[1];
+  f.v = cv.b;
+}
+
+// epilogue of 4 consecutive rows (m..m+3) of one column n: bias, pos, GELU / GELU', residual, fp32 / atomic / bf16 out
+__device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, int m, int n, float bias, bool first_split) {
+  bf16_t* out_t = reinterpret_cast<bf16_t*>(d.out_t);
+  bf16_t* out_pre = reinterpret_cast<bf16_t*>(d.out_pre);
+  const bf16_t* aux = reinterpret_cast<const bf16_t*>(d.aux);
+#pragma unroll
+  for (int r = 0; r < 4; ++r, ++m) {
+    if (m >= d.M) return;
+    float v = a[r] * d.alpha + bias;
+    if (d.pos) v += d.pos[(long)(m % d.pos_period) * d.N + n];
+    if (d.act == S4F_ACT_GELU) {
+      if (out_pre) out_pre[(long)m * d.ldo_pre + n] = (bf16_t)v;
+      v = gelu_f(v);
+    } else if (d.act == S4F_ACT_GELU_BWD) {
+      v *= gelu_grad_f((float)aux[(long)m * d.ld_aux + n]);
+    }
+    if (d.resid && first_split) v += d.resid[(long)m * d.ldr + n];
+    if (d.out_f32) {
+      if (d.atomic) atomicAdd(d.out_f32 + (long)m * d.ldo_f32 + n, v);
+      else d.out_f32[(long)m * d.ldo_f32 + n] = v;
+    }
+    if (out_t) out_t[(long)m * d.ldo_t + n] = (bf16_t)v;
+  }
+}
+
+template <int BN, int AMODE, int BMODE>
+__global__ __launch_bounds__(512) void gemm2_kernel(const GemmArgs args) {
+  constexpr bool AK = (AMODE == S4F_OP_K);
+  constexpr bool BKM = (BMODE == S4F_OP_K || BMODE == S4F_OP_K_TAPSPLIT || BMODE == S4F_OP_K_CONV);
+  constexpr bool TRMAP = AK || BKM;
+  using FA = Feeder<AMODE, true, BM>;
+  using FB = Feeder<BMODE, false, BN>;
+  constexpr int A_BYTES = FA::BYTES, B_BYTES = FB::BYTES;
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NJ = BN / 32;                       // 16-wide column sub-tiles per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE
+
+  const s4f_gemm_desc& d = args.d;
+  // XCD-aware bijective remap of the linear block id (blocks b and b+8 share an XCD / L2)
+  const int nt = args.tiles_m * args.tiles_n;
+  int L = blockIdx.x;
+  {
+    const int xcd = L & 7, q8 = nt >> 3, r8 = nt & 7;
+    const int basei = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    L = basei + (L >> 3);
+  }
+  const int tm = L / args.tiles_n, tn = L - tm * args.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kt_beg = blockIdx.z * args.nk_per_split;
+  int kt_end = kt_beg + args.nk_per_split;
+  if (kt_end > args.nk) kt_end = args.nk;
+
+  FA fa; FB fb;
+  fa.init(d, m0, kt_beg);
+  fb.init(d, n0, kt_beg);
+
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l = threadIdx.x & 63, g = l >> 4, li = l & 15;
+
+  f32x4 acc[4][NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  if (kt_beg < kt_end) {
+    fa.issue(kt_beg, smem);
+    fb.issue(kt_beg, smem + A_BYTES);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = kt_beg; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_beg) & 1;
+    char* As = smem + cur * STAGE;
+    char* Bs = As + A_BYTES;
+    const bool more = kt + 1 < kt_end;
+    char* An = smem + (cur ^ 1) * STAGE;
+    if (more) fa.issue(kt + 1, An);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (s == 1 && more) fb.issue(kt + 1, An + A_BYTES);
+      Frag<bf16_t> a[4], b[NJ];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (AK) frag_k<BM>(a[i], As, wm * 64 + i * 16, s);
+        else frag_row<TRMAP>(a[i], As, wm * 64 + i * 16, s);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        if constexpr (BKM) frag_k<BN>(b[j], Bs, wn * (BN / 2) + j * 16, s);
+        else frag_row<TRMAP>(b[j], Bs, wn * (BN / 2) + j * 16, s);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(a[i], b[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue (same contract as gemm.hip)
+  const bool first_split = (blockIdx.z == 0);
+  static_for<NJ>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int n = n0 + wn * (BN / 2) + j * 16 + li;
+    if (n < d.N) {
+      const float bias = (d.bias && first_split) ? d.bias[n] : 0.f;
+      static_for<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        epilogue_quad(d, acc[i][j], m0 + wm * 64 + i * 16 + 4 * g, n, bias, first_split);
+      });
+    }
+  });
+}
+
+template <int BN, int AM, int BMo>
+int launch(const s4f_gemm_desc& d, hipStream_t st) {
+  GemmArgs a;
+  a.d = d;
+  a.nk = ceil_div(d.K, BK);
+  int sk = d.splitk < 1 ? 1 : d.splitk;
+  if (sk > a.nk) sk = a.nk;
+  a.nk_per_split = ceil_div(a.nk, sk);
+  sk = ceil_div(a.nk, a.nk_per_split);
+  a.tiles_m = ceil_div(d.M, BM);
+  a.tiles_n = ceil_div(d.N, BN);
+  using FA = Feeder<AM, true, BM>;
+  using FB = Feeder<BMo, false, BN>;
+  const size_t shm = 2 * (size_t)(FA::BYTES + FB::BYTES);
+  static bool attr_set = false;
+  auto kern = gemm2_kernel<BN, AM, BMo>;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  dim3 grid(a.tiles_m * a.tiles_n, 1, sk);
+  hipLaunchKernelGGL(kern, grid, dim3(512), shm, st, a);
+  return 0;
+}
+
+template <int BN>
+int dispatch(const s4f_gemm_desc& d, hipStream_t st) {
+  const int am = d.a_mode, bm = d.b_mode;
+  if (am == S4F_OP_ROW && bm == S4F_OP_ROW) return launch<BN, S4F_OP_ROW, S4F_OP_ROW>(d, st);
+  if (am == S4F_OP_ROW && bm == S4F_OP_K) return launch<BN, S4F_OP_ROW, S4F_OP_K>(d, st);
+  if (am == S4F_OP_K && bm == S4F_OP_K) return launch<BN, S4F_OP_K, S4F_OP_K>(d, st);
+  if (am == S4F_OP_ROW_CONV && bm == S4F_OP_ROW) return launch<BN, S4F_OP_ROW_CONV, S4F_OP_ROW>(d, st);
+  if (am == S4F_OP_ROW_CONV && bm == S4F_OP_K_TAPSPLIT) return launch<BN, S4F_OP_ROW_CONV, S4F_OP_K_TAPSPLIT>(d, st);
+  if (am == S4F_OP_K && bm == S4F_OP_K_CONV) return launch<BN, S4F_OP_K, S4F_OP_K_CONV>(d, st);
+  return -100;
+}
+
+}  // namespace g2
+
+// entry used by s4f_gemm (gemm.hip) for bf16 problems: returns -100 when the shape should stay on the 128x128 kernel
+int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn) {
+  if (d.dtype != S4F_BF16) return -100;
+  if (d.b_mode == S4F_OP_K_CONV && (d.cC % 256) != 0 && bn == 256) return -100;   // tap must be uniform per N tile
+  if (bn == 256) return g2::dispatch<256>(d, st);
+  return g2::dispatch<128>(d, st);
+}

@@ -54,7 +54,7 @@ def _chk_f32(t, what):
 
 def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=1.0, bias=None, resid=None, ldr=0,
          out_f32=None, ldo_f32=0, out_t=None, ldo_t=0, out_pre=None, ldo_pre=0, aux=None, ld_aux=0, act=ACT_NONE,
-         atomic=False, splitk=1, conv=None, pos_period=0, pos=None):
+         atomic=False, splitk=1, conv=None, pos_period=0, pos=None, tile_hint=0):
     """C[m,n] = alpha * sum_k A(m,k) B(n,k) + epilogue; see include/s4f.h. conv = (B, H, W, C, sign)."""
     _chk_dtype(A, dtype, 'gemm A'); _chk_dtype(B, dtype, 'gemm B')
     _chk_dtype(out_t, dtype, 'gemm out_t'); _chk_dtype(out_pre, dtype, 'gemm out_pre'); _chk_dtype(aux, dtype, 'gemm aux')
@@ -104,6 +104,7 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
     d.aux, d.ld_aux = p(aux), ld_aux
     d.act, d.atomic = act, 1 if atomic else 0
     d.pos_period, d.pos = pos_period, p(pos)
+    d.tile_hint = tile_hint
     call('s4f_gemm', ctypes.byref(d), stream(), tag=(a_mode, b_mode, M, N, K))
 
 

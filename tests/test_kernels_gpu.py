@@ -466,3 +466,66 @@ def test_ema_sgd(K, code):
         opt.step()
         K.sgd_momentum(pd, dev(g), buf, None, n, lr, 0.9, 1.0, it == 0, code)
     check(pd, p.detach(), 0, 'sgd momentum', tol=2e-7)
+
+
+# ------------------------------------------------------------------------------------------------ 256-row LDS-DMA kernel
+@pytest.mark.parametrize('hint', [2, 3])
+def test_gemm2_dense_modes(K, hint):
+    code = 1
+    M, N, K_ = 1000, 768, 832
+    x, w, b = q(rnd(M, K_, seed=1), code), q(rnd(N, K_, seed=2, scale=0.05), code), rnd(N, seed=3)
+    r = rnd(M, N, seed=4)
+    out = torch.empty(M, N, device='cuda')
+    K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), resid=dev(r), ldr=N, out_f32=out, ldo_f32=N,
+           tile_hint=hint)
+    check(out, r + O.linear(x, w, b), code, f'gemm2 NT hint {hint}')
+    # GELU epilogue + pre-activation
+    out_t = torch.empty(M, N, device='cuda', dtype=tdt(code)); out_pre = torch.empty_like(out_t)
+    K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), out_t=out_t, ldo_t=N, out_pre=out_pre, ldo_pre=N,
+           act=K.ACT_GELU, tile_hint=hint)
+    z = O.linear(x, w, b)
+    check(out_pre, z, code, 'gemm2 gelu pre'); check(out_t, O.gelu(z), code, 'gemm2 gelu out')
+    # NN (B k-major): dx[M, K_] = dy[M, N] w[N, K_]
+    dy = q(rnd(M, N, seed=5), code)
+    dx = torch.empty(M, K_, device='cuda')
+    K.gemm(dev(dy, code), dev(w, code), M, K_, N, N, K_, code, b_mode=K.OP_K, out_f32=dx, ldo_f32=K_, tile_hint=hint)
+    check(dx, dy @ w, code, f'gemm2 NN hint {hint}')
+    # TN (both k-major) with split-K atomics: dW[N, K_] += dy^T x
+    base = rnd(N, K_, seed=6)
+    dw = dev(base.clone())
+    K.gemm(dev(dy, code), dev(x, code), N, K_, M, N, K_, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=dw, ldo_f32=K_, atomic=True,
+           splitk=3, tile_hint=hint)
+    check(dw, base + dy.t() @ x, code, f'gemm2 TN hint {hint}')
+    # ragged small-N (conv_seg shapes): N = 21
+    w21 = q(rnd(21, 256, seed=7, scale=0.05), code); x21 = q(rnd(M, 256, seed=8), code)
+    o21 = torch.zeros(M, 32, device='cuda')
+    K.gemm(dev(x21, code), dev(w21, code), M, 21, 256, 256, 256, code, out_f32=o21, ldo_f32=32, tile_hint=2)
+    check(o21[:, :21], x21 @ w21.t(), code, 'gemm2 N=21')
+    assert float(o21[:, 21:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('hint', [2, 3])
+@pytest.mark.parametrize('Cin,Cout', [(768, 256), (256, 256)])
+def test_gemm2_conv_modes(K, hint, Cin, Cout):
+    code = 1
+    B, H, W = 2, 24, 20
+    x = q(rnd(B, Cin, H, W, seed=1), code)
+    w = q(rnd(Cout, Cin, 3, 3, seed=2, scale=0.03), code)
+    dy = q(rnd(B, Cout, H, W, seed=3), code)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = O.conv3x3(xr, wr)
+    y.backward(dy)
+    M = B * H * W
+    xh, wp, dyh = dev(to_nhwc(x), code), dev(w.permute(0, 2, 3, 1), code), dev(to_nhwc(dy), code)
+    out = torch.empty(M, Cout, device='cuda', dtype=tdt(code))
+    K.gemm(xh, wp, M, Cout, 9 * Cin, Cin, 9 * Cin, code, a_mode=K.OP_ROW_CONV, out_t=out, ldo_t=Cout, conv=(B, H, W, Cin, 1),
+           tile_hint=hint)
+    check(out.reshape(B, H, W, Cout), to_nhwc(y), code, f'gemm2 conv fwd hint {hint}')
+    dx = torch.empty(M, Cin, device='cuda', dtype=tdt(code))
+    K.gemm(dyh, wp, M, Cin, 9 * Cout, Cout, 9 * Cin, code, a_mode=K.OP_ROW_CONV, b_mode=K.OP_K_TAPSPLIT, out_t=dx, ldo_t=Cin,
+           conv=(B, H, W, Cout, -1), tile_hint=hint)
+    check(dx.reshape(B, H, W, Cin), to_nhwc(xr.grad), code, f'gemm2 conv dgrad hint {hint}')
+    dw = torch.zeros(Cout, 9 * Cin, device='cuda')
+    K.gemm(dyh, xh, Cout, 9 * Cin, M, Cout, Cin, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV, out_f32=dw, ldo_f32=9 * Cin, atomic=True,
+           splitk=3, conv=(B, H, W, Cin, 1), tile_hint=hint)
+    check(dw.reshape(Cout, 3, 3, Cin), wr.grad.permute(0, 2, 3, 1), code, f'gemm2 conv wgrad hint {hint}', tol=3e-2)

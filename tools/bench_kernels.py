@@ -41,20 +41,24 @@ def report(name, ms, flops=None, bytes_=None):
 
 B, N, C = 8, 1025, 768
 M = B * N
+HINTS = (1, 2, 3) if code else (1,)
 for (n, k, nm) in [(2304, 768, 'qkv'), (768, 768, 'proj'), (3072, 768, 'fc1'), (768, 3072, 'fc2')]:
     x, w = rt(M, k), rt(n, k, scale=0.02)
     out = torch.empty(M, n, device=dev, dtype=T)
-    ms = timeit(lambda: K.gemm(x, w, M, n, k, k, k, code, out_t=out, ldo_t=n))
-    report(f'gemm NT {nm} [{M}x{n}x{k}]', ms, 2.0 * M * n * k)
     dy = rt(M, n)
     dx = torch.empty(M, k, device=dev, dtype=T)
-    ms = timeit(lambda: K.gemm(dy, w, M, k, n, n, k, code, b_mode=K.OP_K, out_t=dx, ldo_t=k))
-    report(f'gemm NN dgrad {nm}', ms, 2.0 * M * n * k)
     dw = torch.zeros(n, k, device=dev)
-    for sk in (1, 2, 4):
-        ms = timeit(lambda: K.gemm(dy, x, n, k, M, n, k, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=dw, ldo_f32=k,
-                                   atomic=True, splitk=sk))
-        report(f'gemm TN wgrad {nm} splitk={sk}', ms, 2.0 * M * n * k)
+    for h in HINTS:
+        ms = timeit(lambda: K.gemm(x, w, M, n, k, k, k, code, out_t=out, ldo_t=n, tile_hint=h))
+        report(f'gemm NT {nm} [{M}x{n}x{k}] hint{h}', ms, 2.0 * M * n * k)
+    for h in HINTS:
+        ms = timeit(lambda: K.gemm(dy, w, M, k, n, n, k, code, b_mode=K.OP_K, out_t=dx, ldo_t=k, tile_hint=h))
+        report(f'gemm NN dgrad {nm} hint{h}', ms, 2.0 * M * n * k)
+    for h in HINTS:
+        for sk in (1, 2, 4, 8):
+            ms = timeit(lambda: K.gemm(dy, x, n, k, M, n, k, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=dw, ldo_f32=k,
+                                       atomic=True, splitk=sk, tile_hint=h))
+            report(f'gemm TN wgrad {nm} splitk={sk} hint{h}', ms, 2.0 * M * n * k)
 
 H = 12
 qkv = rt(B, N, 3 * C)
@@ -71,19 +75,22 @@ for (cin, cout, hw) in [(768, 256, 32), (256, 256, 64), (256, 256, 128), (256, 2
     x, w = rt(Mp, cin), rt(cout, 9 * cin, scale=0.02)
     y = torch.empty(Mp, cout, device=dev, dtype=T)
     fl = 2.0 * Mp * cout * 9 * cin
-    ms = timeit(lambda: K.gemm(x, w, Mp, cout, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_t=y, ldo_t=cout,
-                               conv=(B, hw, hw, cin, 1)), iters=5)
-    report(f'conv3x3 fwd {cin}->{cout} @{hw}', ms, fl)
     dy = rt(Mp, cout)
     dx = torch.empty(Mp, cin, device=dev, dtype=T)
-    ms = timeit(lambda: K.gemm(dy, w, Mp, cin, 9 * cout, cout, 9 * cin, code, a_mode=K.OP_ROW_CONV, b_mode=K.OP_K_TAPSPLIT,
-                               out_t=dx, ldo_t=cin, conv=(B, hw, hw, cout, -1)), iters=5)
-    report(f'conv3x3 dgrad @{hw}', ms, fl)
     dw = torch.zeros(cout, 9 * cin, device=dev)
-    sk = max(1, min(64, Mp // 4096))
-    ms = timeit(lambda: K.gemm(dy, x, cout, 9 * cin, Mp, cout, cin, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV, out_f32=dw,
-                               ldo_f32=9 * cin, atomic=True, splitk=sk, conv=(B, hw, hw, cin, 1)), iters=5)
-    report(f'conv3x3 wgrad @{hw} splitk={sk}', ms, fl)
+    for h in HINTS:
+        ms = timeit(lambda: K.gemm(x, w, Mp, cout, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_t=y, ldo_t=cout,
+                                   conv=(B, hw, hw, cin, 1), tile_hint=h), iters=5)
+        report(f'conv3x3 fwd {cin}->{cout} @{hw} hint{h}', ms, fl)
+    for h in HINTS:
+        ms = timeit(lambda: K.gemm(dy, w, Mp, cin, 9 * cout, cout, 9 * cin, code, a_mode=K.OP_ROW_CONV, b_mode=K.OP_K_TAPSPLIT,
+                                   out_t=dx, ldo_t=cin, conv=(B, hw, hw, cout, -1), tile_hint=h), iters=5)
+        report(f'conv3x3 dgrad @{hw} hint{h}', ms, fl)
+    for h in HINTS:
+        for sk in sorted({max(1, min(64, Mp // 4096)), max(1, min(64, Mp // 16384)), max(1, min(16, Mp // 65536))}):
+            ms = timeit(lambda: K.gemm(dy, x, cout, 9 * cin, Mp, cout, cin, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV, out_f32=dw,
+                                       ldo_f32=9 * cin, atomic=True, splitk=sk, conv=(B, hw, hw, cin, 1), tile_hint=h), iters=5)
+            report(f'conv3x3 wgrad @{hw} splitk={sk} hint{h}', ms, fl)
 
 # memory-bound members
 x = torch.randn(M, C, device=dev)

@@ -1,0 +1,46 @@
+"""run one kernel shape a few times (for rocprofv3 --pmc / kernel-trace): python tools/one_kernel.py <what> <hint>"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from s4former_amd import kernels as K  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else 'conv4'
+hint = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+T = torch.bfloat16
+B = 8
+if what == 'conv4':
+    hw, cin, cout = 256, 256, 256
+    Mp = B * hw * hw
+    x = torch.randn(Mp, cin, device='cuda').to(T)
+    w = (torch.randn(cout, 9 * cin, device='cuda') * 0.02).to(T)
+    y = torch.empty(Mp, cout, device='cuda', dtype=T)
+    def run():
+        K.gemm(x, w, Mp, cout, 9 * cin, cin, 9 * cin, 1, a_mode=K.OP_ROW_CONV, out_t=y, ldo_t=cout, conv=(B, hw, hw, cin, 1), tile_hint=hint)
+elif what == 'big':      # plain NT 8192^2 x 4096: no gather, no edge
+    M, N, Kd = 8192, 8192, 4096
+    x = torch.randn(M, Kd, device='cuda').to(T)
+    w = (torch.randn(N, Kd, device='cuda') * 0.02).to(T)
+    y = torch.empty(M, N, device='cuda', dtype=T)
+    def run():
+        K.gemm(x, w, M, N, Kd, Kd, Kd, 1, out_t=y, ldo_t=N, tile_hint=hint)
+else:
+    M, N, Kd = 8200, 3072, 768
+    x = torch.randn(M, Kd, device='cuda').to(T)
+    w = (torch.randn(N, Kd, device='cuda') * 0.02).to(T)
+    y = torch.empty(M, N, device='cuda', dtype=T)
+    def run():
+        K.gemm(x, w, M, N, Kd, Kd, Kd, 1, out_t=y, ldo_t=N, tile_hint=hint)
+for _ in range(2):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(iters):
+    run()
+e1.record()
+torch.cuda.synchronize()
+print(what, 'hint', hint, 'ms', e0.elapsed_time(e1) / iters)
