@@ -79,7 +79,7 @@ typedef struct s4f_gemm_desc {
   int32_t pos_period;
   const float* pos;         /* fp32 [pos_period, N] or NULL */
   /* kernel selection: 0 = automatic; 1 = 128x128 register-staged kernel; 2 = 256x128 LDS-DMA kernel;
-   * 3 = 256x256 LDS-DMA kernel (2 and 3: bf16 only) */
+   * 3 = 256x256 LDS-DMA kernel, 8 waves; 4 = 256x256, 16 waves (2-4: bf16 only) */
   int32_t tile_hint;
 } s4f_gemm_desc;
 

@@ -327,7 +327,7 @@ static int pick_tile(const s4f_gemm_desc& d) {
   if (d.dtype != S4F_BF16) return 0;
   if (d.tile_hint == 1) return 0;
   if (d.tile_hint == 2) return 128;
-  if (d.tile_hint == 3) return 256;
+  if (d.tile_hint == 3 || d.tile_hint == 4) return 256;
   const long sk = d.splitk < 1 ? 1 : d.splitk;
   const long t256 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 256) * sk;
   const long t128 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 128) * sk;

@@ -48,11 +48,11 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 // One feeder per operand: NSLOT DMA slots per thread per k-iteration.  All per-slot address arithmetic is
 // incremental: a slot keeps a byte pointer that advances by a constant per k-iteration; the conv modes
 // recompute it only when the tap changes (a wave-uniform branch every cC/64 iterations).
-template <int MODE, bool IS_A, int EXT>   // EXT = rows (row-major) or columns (k-major) of the tile
+template <int MODE, bool IS_A, int EXT, int NW>   // EXT = rows (row-major) or columns (k-major) of the tile
 struct Feeder {
   static constexpr bool KM = (MODE == S4F_OP_K || MODE == S4F_OP_K_TAPSPLIT || MODE == S4F_OP_K_CONV);
   static constexpr int NG = KM ? KImg<EXT>::NG : RImg<EXT>::NG;
-  static constexpr int NSLOT = NG / 8;
+  static constexpr int NSLOT = NG / NW;
   static constexpr int BYTES = KM ? KImg<EXT>::BYTES : RImg<EXT>::BYTES;
   static constexpr int GSTRIDE = KM ? KImg<EXT>::GS : 1024;
 
@@ -98,7 +98,7 @@ struct Feeder {
     const int k0 = kt0 * BK;
 #pragma unroll
     for (int u = 0; u < NSLOT; ++u) {
-      const int t = wave + 8 * u;
+      const int t = wave + NW * u;
       ok[u] = true;
       if constexpr (!KM) {
         const int row = 8 * t + (lane >> 3);
@@ -142,7 +142,7 @@ struct Feeder {
     }
 #pragma unroll
     for (int u = 0; u < NSLOT; ++u) {
-      const int t = wave + 8 * u;
+      const int t = wave + NW * u;
       char* dst = img + t * GSTRIDE;
       const char* src;
       if constexpr (MODE == S4F_OP_K_CONV) {
@@ -222,16 +222,18 @@ __device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, i
   }
 }
 
-template <int BN, int AMODE, int BMODE>
-__global__ __launch_bounds__(512) void gemm2_kernel(const GemmArgs args) {
+template <int BN, int AMODE, int BMODE, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
   constexpr bool AK = (AMODE == S4F_OP_K);
   constexpr bool BKM = (BMODE == S4F_OP_K || BMODE == S4F_OP_K_TAPSPLIT || BMODE == S4F_OP_K_CONV);
   constexpr bool TRMAP = AK || BKM;
-  using FA = Feeder<AMODE, true, BM>;
-  using FB = Feeder<BMODE, false, BN>;
+  using FA = Feeder<AMODE, true, BM, NW>;
+  using FB = Feeder<BMODE, false, BN, NW>;
   constexpr int A_BYTES = FA::BYTES, B_BYTES = FB::BYTES;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int NJ = BN / 32;                       // 16-wide column sub-tiles per wave
+  constexpr int WN = NW / 4;                        // waves along N (4 along M)
+  constexpr int WTN = BN / WN;                      // wave tile width
+  constexpr int NJ = WTN / 16;                      // 16-wide column sub-tiles per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE
 
   const s4f_gemm_desc& d = args.d;
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmArgs args) {
   fb.init(d, n0, kt_beg);
 
   const int wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l = threadIdx.x & 63, g = l >> 4, li = l & 15;
 
   f32x4 acc[4][NJ];
@@ -288,8 +290,8 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmArgs args) {
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        if constexpr (BKM) frag_k<BN>(b[j], Bs, wn * (BN / 2) + j * 16, s);
-        else frag_row<TRMAP>(b[j], Bs, wn * (BN / 2) + j * 16, s);
+        if constexpr (BKM) frag_k<BN>(b[j], Bs, wn * WTN + j * 16, s);
+        else frag_row<TRMAP>(b[j], Bs, wn * WTN + j * 16, s);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -302,9 +304,116 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmArgs args) {
 
   // ------------------------------------------------------------------ epilogue (same contract as gemm.hip)
   const bool first_split = (blockIdx.z == 0);
+  // Fast path: the tile goes through LDS (fp32, two passes of 128 rows) and leaves with 16-byte-per-lane row-
+  // contiguous accesses (outputs, residual, aux, pos all coalesced).  A 2-byte-per-lane store of the raw C layout
+  // costs one memory instruction per 64 elements: ~1000 store instructions per tile, the dominant cost at K = 768.
+  const bool wide = (d.N % 8 == 0) && (n0 + BN <= d.N) && (!d.atomic || (BMODE != S4F_OP_K_CONV && d.act == S4F_ACT_NONE && !d.out_t && !d.pos)) &&
+                    (!d.out_t || d.ldo_t % 8 == 0) && (!d.out_pre || d.ldo_pre % 8 == 0) && (!d.aux || d.ld_aux % 8 == 0) &&
+                    (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % 4 == 0);
+  if (wide) {
+    constexpr int LDT = BN + 4;                    // fp32 row stride of the staging tile (pad: rows 4 apart -> other banks)
+    float* tile = reinterpret_cast<float*>(smem);
+    constexpr int CPR = BN / 8;                    // 8-column chunks per row
+    constexpr int ITEMS = 128 * CPR / (64 * NW);   // chunk items per thread per pass
+    bf16_t* out_t = reinterpret_cast<bf16_t*>(d.out_t);
+    bf16_t* out_pre = reinterpret_cast<bf16_t*>(d.out_pre);
+    const bf16_t* aux = reinterpret_cast<const bf16_t*>(d.aux);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      __syncthreads();
+      if ((wm >> 1) == pass) {
+        const int rbase = (wm & 1) * 64;
+        static_for<NJ>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const int col = wn * WTN + j * 16 + li;
+          static_for<4>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(rbase + i * 16 + 4 * g + r) * LDT + col] = acc[i][j][r];
+          });
+        });
+      }
+      __syncthreads();
+      if (d.atomic) {
+        // split-K partial sums: fp32 atomics, each wave-instruction covers 64 consecutive columns (256 B) of one row
+        constexpr int AITEMS = 128 * BN / (64 * NW);
+#pragma unroll 4
+        for (int it = 0; it < AITEMS; ++it) {
+          const int idx = threadIdx.x + it * 64 * NW;
+          const int row = idx / BN, col = idx % BN;
+          const int m = m0 + pass * 128 + row;
+          if (m >= d.M) continue;
+          float v = tile[row * LDT + col] * d.alpha;
+          if (first_split) {
+            if (d.bias) v += d.bias[n0 + col];
+            if (d.resid) v += d.resid[(long)m * d.ldr + n0 + col];
+          }
+          atomicAdd(d.out_f32 + (long)m * d.ldo_f32 + n0 + col, v);
+        }
+        continue;
+      }
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        const int idx = threadIdx.x + it * 64 * NW;
+        const int row = idx / CPR, cc = idx % CPR;
+        const int m = m0 + pass * 128 + row;
+        if (m >= d.M) continue;
+        const int n = n0 + cc * 8;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cc * 8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cc * 8 + 4);
+        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        if (d.bias && first_split) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + n), b1 = *reinterpret_cast<const f32x4*>(d.bias + n + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = v[e] * d.alpha + b0[e]; v[4 + e] = v[4 + e] * d.alpha + b1[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= d.alpha;
+        }
+        if (d.pos) {
+          const float* pp = d.pos + (long)(m % d.pos_period) * d.N + n;
+          const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
+        }
+        if (d.act == S4F_ACT_GELU) {
+          if (out_pre) {
+            bf16x8 pv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = (bf16_t)v[e];
+            *reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n) = pv;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+        } else if (d.act == S4F_ACT_GELU_BWD) {
+          const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)z[e]);
+        }
+        if (d.resid && first_split) {
+          const float* rp = d.resid + (long)m * d.ldr + n;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        }
+        if (d.out_f32) {
+          float* op = d.out_f32 + (long)m * d.ldo_f32 + n;
+          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        if (out_t) {
+          bf16x8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x8*>(out_t + (long)m * d.ldo_t + n) = ov;
+        }
+      }
+    }
+    return;
+  }
   static_for<NJ>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    const int n = n0 + wn * (BN / 2) + j * 16 + li;
+    const int n = n0 + wn * WTN + j * 16 + li;
     if (n < d.N) {
       const float bias = (d.bias && first_split) ? d.bias[n] : 0.f;
       static_for<4>([&](auto ic) {
@@ -315,7 +424,7 @@ __global__ __launch_bounds__(512) void gemm2_kernel(const GemmArgs args) {
   });
 }
 
-template <int BN, int AM, int BMo>
+template <int BN, int AM, int BMo, int NW>
 int launch(const s4f_gemm_desc& d, hipStream_t st) {
   GemmArgs a;
   a.d = d;
@@ -326,29 +435,31 @@ int launch(const s4f_gemm_desc& d, hipStream_t st) {
   sk = ceil_div(a.nk, a.nk_per_split);
   a.tiles_m = ceil_div(d.M, BM);
   a.tiles_n = ceil_div(d.N, BN);
-  using FA = Feeder<AM, true, BM>;
-  using FB = Feeder<BMo, false, BN>;
-  const size_t shm = 2 * (size_t)(FA::BYTES + FB::BYTES);
+  using FA = Feeder<AM, true, BM, NW>;
+  using FB = Feeder<BMo, false, BN, NW>;
+  size_t shm = 2 * (size_t)(FA::BYTES + FB::BYTES);
+  const size_t epi = (size_t)128 * (BN + 4) * 4;          // fp32 staging tile of the coalesced epilogue
+  if (shm < epi) shm = epi;
   static bool attr_set = false;
-  auto kern = gemm2_kernel<BN, AM, BMo>;
+  auto kern = gemm2_kernel<BN, AM, BMo, NW>;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
   dim3 grid(a.tiles_m * a.tiles_n, 1, sk);
-  hipLaunchKernelGGL(kern, grid, dim3(512), shm, st, a);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * NW), shm, st, a);
   return 0;
 }
 
-template <int BN>
+template <int BN, int NW>
 int dispatch(const s4f_gemm_desc& d, hipStream_t st) {
   const int am = d.a_mode, bm = d.b_mode;
-  if (am == S4F_OP_ROW && bm == S4F_OP_ROW) return launch<BN, S4F_OP_ROW, S4F_OP_ROW>(d, st);
-  if (am == S4F_OP_ROW && bm == S4F_OP_K) return launch<BN, S4F_OP_ROW, S4F_OP_K>(d, st);
-  if (am == S4F_OP_K && bm == S4F_OP_K) return launch<BN, S4F_OP_K, S4F_OP_K>(d, st);
-  if (am == S4F_OP_ROW_CONV && bm == S4F_OP_ROW) return launch<BN, S4F_OP_ROW_CONV, S4F_OP_ROW>(d, st);
-  if (am == S4F_OP_ROW_CONV && bm == S4F_OP_K_TAPSPLIT) return launch<BN, S4F_OP_ROW_CONV, S4F_OP_K_TAPSPLIT>(d, st);
-  if (am == S4F_OP_K && bm == S4F_OP_K_CONV) return launch<BN, S4F_OP_K, S4F_OP_K_CONV>(d, st);
+  if (am == S4F_OP_ROW && bm == S4F_OP_ROW) return launch<BN, S4F_OP_ROW, S4F_OP_ROW, NW>(d, st);
+  if (am == S4F_OP_ROW && bm == S4F_OP_K) return launch<BN, S4F_OP_ROW, S4F_OP_K, NW>(d, st);
+  if (am == S4F_OP_K && bm == S4F_OP_K) return launch<BN, S4F_OP_K, S4F_OP_K, NW>(d, st);
+  if (am == S4F_OP_ROW_CONV && bm == S4F_OP_ROW) return launch<BN, S4F_OP_ROW_CONV, S4F_OP_ROW, NW>(d, st);
+  if (am == S4F_OP_ROW_CONV && bm == S4F_OP_K_TAPSPLIT) return launch<BN, S4F_OP_ROW_CONV, S4F_OP_K_TAPSPLIT, NW>(d, st);
+  if (am == S4F_OP_K && bm == S4F_OP_K_CONV) return launch<BN, S4F_OP_K, S4F_OP_K_CONV, NW>(d, st);
   return -100;
 }
 
@@ -358,6 +469,6 @@ int dispatch(const s4f_gemm_desc& d, hipStream_t st) {
 int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn) {
   if (d.dtype != S4F_BF16) return -100;
   if (d.b_mode == S4F_OP_K_CONV && (d.cC % 256) != 0 && bn == 256) return -100;   // tap must be uniform per N tile
-  if (bn == 256) return g2::dispatch<256>(d, st);
-  return g2::dispatch<128>(d, st);
+  if (bn == 256) return d.tile_hint == 4 ? g2::dispatch<256, 16>(d, st) : g2::dispatch<256, 8>(d, st);
+  return g2::dispatch<128, 8>(d, st);
 }

@@ -314,6 +314,14 @@ class EncoderDecoder(BaseSegmentor):
                 self.update_ema_variables()
 
         sup_imgs = sup_gts = None
+        do_unsup = ('unsup_student' in data_groups) and self.unsup_weight != 0
+        fused = 'sup' in data_groups and do_unsup and self.ema and (self.attn_mask_seperate_head or self.plain_mt_pseudo_loss)
+        if fused:
+            # One backbone pass for the supervised and the unlabeled-student images (every backbone op is per image;
+            # the heads, whose BatchNorm statistics are per call (Q10), still run per group).  Same arithmetic as the
+            # reference's separate extract_feat calls, twice the GEMM rows per launch.
+            self._fused_step(data_groups)
+            return self.losses
         if 'sup' in data_groups:
             sup_imgs = data_groups['sup']['img']
             sup_gts = data_groups['sup']['gt_semantic_seg']
@@ -323,27 +331,18 @@ class EncoderDecoder(BaseSegmentor):
                 self.losses.update(self._auxiliary_head_forward_train(labeled_features, data_groups['sup']['img_metas'], sup_gts))
             self.losses.update(loss_decode_sup)
 
-        if ('unsup_student' in data_groups) and self.unsup_weight != 0:
+        if do_unsup:
             unsup_loss = weighted_loss(
                 self.foward_unsup_train(data_groups['unsup_teacher'], data_groups['unsup_student'], sup_imgs, sup_gts),
                 weight=self.unsup_weight)
             if self.iter_unsup_start != 0:
-                if current_iter > self.iter_unsup_start:
+                if self.current_iter > self.iter_unsup_start:
                     self.losses.update(unsup_loss)
             else:
                 self.losses.update(unsup_loss)
         return self.losses
 
-    def _conf_to_patch_u(self, conf_mask):
-        """encoder_decoder.py:547-555: per-patch mean of (1 - conf) -> [B, gh, gw] (Q12: square crops)"""
-        ps = self.patchsize
-        Bn, H, W = conf_mask.shape
-        c = conf_mask.view(Bn, H // ps, ps, W // ps, ps).to(torch.float32)
-        return (1.0 - c).sum(dim=(2, 4)) / (ps * ps)
-
-    def foward_unsup_train(self, teacher_data, student_data, sup_imgs, sup_gts):
-        """encoder_decoder.py:516-687 (mean-teacher branch; the in-model strong augmentations are 'next' rows)"""
-        loss_unsup = {}
+    def _teacher_pass(self, teacher_data, student_data):
         tnames = [meta['filename'] for meta in teacher_data['img_metas']]
         snames = [meta['filename'] for meta in student_data['img_metas']]
         tidx = [tnames.index(name) for name in snames]
@@ -356,6 +355,66 @@ class EncoderDecoder(BaseSegmentor):
                 raise S4FError('the teacher of this build is the EMA model (ema=True in all three SETR configs)')
             teacher_info = self.extract_teacher_info_ema(timg, [teacher_data['img_metas'][i] for i in tidx])
             self.set_train(self.ema)
+        return teacher_info
+
+    def _fused_step(self, data_groups):
+        sup, stu = data_groups['sup'], data_groups['unsup_student']
+        teacher_info = self._teacher_pass(data_groups['unsup_teacher'], stu)
+        sup_imgs, simg = sup['img'], stu['img']
+        ns, nu = sup_imgs.shape[0], simg.shape[0]
+        u = self._conf_to_patch_u(teacher_info['conf_mask'])
+        bu, flag, w = self.backbone._rank1_mask(u, self.attn_mask_weight, self.adaptive_attn_mask)
+        groups = [sup_imgs, simg] + ([simg] if self.attn_mask_seperate_head else [])
+        nb = sum(g.shape[0] for g in groups)
+        # the batch usually is [sup..., unsup_student..., unsup_teacher...]: sup + student is then one contiguous view
+        if not self.attn_mask_seperate_head and sup_imgs.data_ptr() + sup_imgs.numel() * 4 == simg.data_ptr() and \
+                sup_imgs._base is not None and sup_imgs._base is simg._base:
+            base = sup_imgs._base
+            off = (sup_imgs.data_ptr() - base.data_ptr()) // (4 * sup_imgs[0].numel())
+            imgs = base[off:off + nb]
+        else:
+            imgs = torch.cat(groups, 0)
+        N = bu.shape[1]
+        bias_u = torch.zeros(nb, N, device=imgs.device)
+        bias_u[ns:ns + nu] = bu
+        row_flag = None
+        if flag is not None:
+            row_flag = torch.ones(nb, N, device=imgs.device)
+            row_flag[ns:ns + nu] = flag
+        outs = self.backbone.forward_rank1(imgs, (bias_u, row_flag, w))
+        f_sup = self.backbone.split_taps(outs, 0, ns)
+        f_mask = self.backbone.split_taps(outs, ns, ns + nu)
+        # supervised heads
+        loss_decode_sup = self._decode_head_forward_train(f_sup, sup['img_metas'], sup['gt_semantic_seg'])
+        if self.with_auxiliary_head:
+            self.losses.update(self._auxiliary_head_forward_train(f_sup, sup['img_metas'], sup['gt_semantic_seg']))
+        self.losses.update(loss_decode_sup)
+        # unsupervised heads (same order of head calls as the reference: sup, masked-unsup, plain-unsup)
+        loss_unsup = {}
+        student_info = dict(img=simg, img_metas=stu['img_metas'], backbone_feature=f_mask)
+        if self.attn_mask_seperate_head:
+            loss_unsup['loss_seg_unsup_attn_mask'] = self.compute_pseudo_loss(student_info, teacher_info)['loss_seg_unsup'] * 0.5
+            student_info['backbone_feature'] = self.backbone.split_taps(outs, ns + nu, ns + 2 * nu)
+        losses = self.compute_pseudo_loss(student_info, teacher_info)
+        loss_unsup['loss_seg_unsup'] = losses['loss_seg_unsup'] * self.fdrop_loss_weight
+        unsup_loss = weighted_loss(loss_unsup, weight=self.unsup_weight)
+        if self.iter_unsup_start != 0:
+            if self.current_iter > self.iter_unsup_start:
+                self.losses.update(unsup_loss)
+        else:
+            self.losses.update(unsup_loss)
+
+    def _conf_to_patch_u(self, conf_mask):
+        """encoder_decoder.py:547-555: per-patch mean of (1 - conf) -> [B, gh, gw] (Q12: square crops)"""
+        ps = self.patchsize
+        Bn, H, W = conf_mask.shape
+        c = conf_mask.view(Bn, H // ps, ps, W // ps, ps).to(torch.float32)
+        return (1.0 - c).sum(dim=(2, 4)) / (ps * ps)
+
+    def foward_unsup_train(self, teacher_data, student_data, sup_imgs, sup_gts):
+        """encoder_decoder.py:516-687 (mean-teacher branch; the in-model strong augmentations are 'next' rows)"""
+        loss_unsup = {}
+        teacher_info = self._teacher_pass(teacher_data, student_data)
         # (hard_seg_label already carries 255 where conf_mask == 0: encoder_decoder.py:541-542 is fused in K15)
         student_info = dict(img=student_data['img'], img_metas=student_data['img_metas'])
 

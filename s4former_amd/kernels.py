@@ -2,6 +2,7 @@
 (every operand extent is checked against what the kernel's grid will touch before anything is launched),
 raw pointers + current stream passed through ctypes.  No torch math here."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -52,10 +53,64 @@ def _chk_f32(t, what):
         raise S4FError(f'{what}: must be float32, got {t.dtype}')
 
 
+# ------------------------------------------------------------------------------------------------ GEMM autotuner
+# Like the reference's cudnn_benchmark=True (configs/_base_/default_runtime.py:17): the first time a GEMM
+# signature is seen, the tile variants (128x128 register-staged / 256x128 / 256x256 LDS-DMA) and, for split-K
+# weight gradients, a few split factors are timed with HIP events and the fastest is remembered.
+AUTOTUNE = os.environ.get('S4F_AUTOTUNE', '1') != '0'
+_TUNED = {}
+
+
+def _tune_gemm(key, run, candidates):
+    best, best_t = candidates[0], None
+    for cand in candidates:
+        try:
+            run(*cand)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                run(*cand)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1)
+        except S4FError:
+            continue
+        if best_t is None or t < best_t:
+            best, best_t = cand, t
+    _TUNED[key] = best
+    return best
+
+
 def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=1.0, bias=None, resid=None, ldr=0,
          out_f32=None, ldo_f32=0, out_t=None, ldo_t=0, out_pre=None, ldo_pre=0, aux=None, ld_aux=0, act=ACT_NONE,
          atomic=False, splitk=1, conv=None, pos_period=0, pos=None, tile_hint=0):
     """C[m,n] = alpha * sum_k A(m,k) B(n,k) + epilogue; see include/s4f.h. conv = (B, H, W, C, sign)."""
+    if tile_hint == 0 and dtype == BF16 and AUTOTUNE:
+        key = (a_mode, b_mode, M, N, K, lda, ldb, conv, act, bool(atomic), out_f32 is not None, out_t is not None,
+               resid is not None, splitk)
+        choice = _TUNED.get(key)
+        if choice is None and L._prof is not None:
+            choice = (0, splitk)
+        if choice is None:
+            hints = [1, 2] + ([3, 4] if N % 256 == 0 and (b_mode != OP_K_CONV or conv[3] % 256 == 0) else [])
+            bk = 64
+            nk = (K + bk - 1) // bk
+            sks = sorted({max(1, min(nk, s_)) for s_ in ((splitk // 2, splitk, splitk * 2, splitk * 4) if atomic else (splitk,))})
+            tmp = torch.empty_like(out_f32) if (atomic and out_f32 is not None) else None
+
+            def run(h, sk):
+                _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, resid, ldr,
+                             tmp if tmp is not None else out_f32, ldo_f32, out_t, ldo_t, out_pre, ldo_pre, aux, ld_aux, act,
+                             atomic, sk, conv, pos_period, pos, h)
+            choice = _tune_gemm(key, run, [(h, sk) for h in hints for sk in sks])
+        tile_hint, splitk = choice
+    _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, resid, ldr, out_f32, ldo_f32, out_t, ldo_t,
+                 out_pre, ldo_pre, aux, ld_aux, act, atomic, splitk, conv, pos_period, pos, tile_hint)
+
+
+def _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, resid, ldr, out_f32, ldo_f32, out_t, ldo_t,
+                 out_pre, ldo_pre, aux, ld_aux, act, atomic, splitk, conv, pos_period, pos, tile_hint):
     _chk_dtype(A, dtype, 'gemm A'); _chk_dtype(B, dtype, 'gemm B')
     _chk_dtype(out_t, dtype, 'gemm out_t'); _chk_dtype(out_pre, dtype, 'gemm out_pre'); _chk_dtype(aux, dtype, 'gemm aux')
     _chk_f32(bias, 'gemm bias'); _chk_f32(resid, 'gemm resid'); _chk_f32(out_f32, 'gemm out_f32'); _chk_f32(pos, 'gemm pos')

@@ -272,6 +272,15 @@ class VisionTransformer(BaseModule):
                 attn_mask=None, attn_mask_weight=0.0, adaptive_attn_mask=False):
         if no_pos_embed or avg_pos_emd or duplicate_pos_emd or use_fdrop:
             raise S4FError('position-embedding ablations / fdrop are outside the hot path (SURVEY §8)')
+        mask = None
+        if attn_mask is not None and self.with_cls_token:
+            mask = self._rank1_mask(attn_mask, attn_mask_weight, adaptive_attn_mask)
+        return self.forward_rank1(inputs, mask)
+
+    def forward_rank1(self, inputs, mask=None):
+        """forward with the PASA mask already in rank-1 form (bias_u [B,N], row_flag [B,N] | None, weight) | None.
+        The segmentor uses this to push several image groups (supervised, masked / plain unlabeled) through the
+        backbone in ONE pass: every backbone op is per image, rows of images without a mask carry u = 0."""
         if not inputs.is_cuda:
             raise S4FError('VisionTransformer runs on the HIP kernels only: move the model and inputs to the GPU')
         store = self._ensure_store(inputs.device)
@@ -280,24 +289,32 @@ class VisionTransformer(BaseModule):
         hw_shape = (H // self.patch_size, W // self.patch_size)
         pe = self.patch_embed.projection
         tokens = PatchEmbedFn.apply(x, pe.weight, pe.bias, self.cls_token, self.pos_embed, store)
-        mask = None
-        if attn_mask is not None and self.with_cls_token:
-            mask = self._rank1_mask(attn_mask, attn_mask_weight, adaptive_attn_mask)
         outs = []
         for i, layer in enumerate(self.layers):
             tokens = layer(tokens, mask)
             if i in self.out_indices:
-                C = tokens.shape[-1]
-                # [B, C, h, w] view of the patch tokens (vit.py:555-562 without the copy); the token tensor rides
-                # along so that the SETR head can read it token-major
-                out = tokens[:, 1:].reshape(B, hw_shape[0], hw_shape[1], C).permute(0, 3, 1, 2)
-                out._s4f_tokens = tokens
-                out._s4f_grid = hw_shape
-                if self.output_cls_token:
-                    out = [out, tokens[:, 0]]
-                outs.append(out)
+                outs.append(self.tap_view(tokens, hw_shape))
         self.multi_self_attn = [[], hw_shape]
         return tuple(outs)
+
+    def tap_view(self, tokens, hw_shape):
+        """[B, C, h, w] view of the patch tokens (vit.py:555-562 without the copy); the token tensor rides along so
+        that the SETR head can read it token-major"""
+        B, _, C = tokens.shape
+        out = tokens[:, 1:].reshape(B, hw_shape[0], hw_shape[1], C).permute(0, 3, 1, 2)
+        out._s4f_tokens = tokens
+        out._s4f_grid = hw_shape
+        if self.output_cls_token:
+            out = [out, tokens[:, 0]]
+        return out
+
+    def split_taps(self, outs, a, b):
+        """taps of the images [a, b) of a multi-group pass"""
+        res = []
+        for o in outs:
+            t = o._s4f_tokens[a:b]
+            res.append(self.tap_view(t, o._s4f_grid))
+        return tuple(res)
 
     def train(self, mode=True):
         super().train(mode)
