@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(PKG_DIR, 'libs4f_hip.so')
 SOURCES = ['gemm.hip', 'gemm2.hip', 'attention.hip', 'elementwise.hip', 'head.hip']
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 's4f.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off',
-         '-Wno-unused-result']
+         '-Wno-unused-result', '-Wno-unused-value', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
 
 
 def _hipcc():

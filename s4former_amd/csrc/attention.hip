@@ -10,6 +10,7 @@
 // The dK/dV kernel computes S = Q K^T (key on the lane) for the same reason.
 #include "common.h"
 #include "../../include/s4f.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -73,15 +74,63 @@ struct AttnArgs {
   int B, N, H;
 };
 
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+constexpr float kScale2 = 0.125f * kLog2e;       // (1/8) * log2(e): scores are kept in log2 units
+
+template <typename T> __device__ __forceinline__ float fexp2(float x);
+template <> __device__ __forceinline__ float fexp2<float>(float x) { return exp2f(x); }
+template <> __device__ __forceinline__ float fexp2<bf16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// register-staged prefetch of a [64][64] tile: NCH chunks of 16 B per thread.  Per-chunk source pointers are kept
+// and advanced by 64 rows per tile; only the ragged last tile pays for row masking (wave-uniform branch).
+template <typename T, int NT> struct TilePF {
+  using C = ACfg<T>;
+  static constexpr int NCH = 64 * C::CPR / NT;
+  chunk16 r[NCH];
+  const T* p[NCH];
+  int loff[NCH];
+  long step;
+  __device__ __forceinline__ void init(const T* src, long ld) {
+    step = 64 * ld;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = threadIdx.x + i * NT;
+      const int row = c / C::CPR, cc = c % C::CPR;
+      p[i] = src + (long)row * ld + cc * C::EPC;
+      loff[i] = row * C::STRIDE + cc * 16;
+    }
+  }
+  // tile starting at row0 = 64 * t (pointers already there); rows >= nrows read as zero
+  __device__ __forceinline__ void load(int row0, int nrows) {
+    if (row0 + 64 <= nrows) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) r[i] = ld_global16(p[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int row = (threadIdx.x + i * NT) / C::CPR;
+        r[i] = (row0 + row < nrows) ? ld_global16(p[i]) : zero16();
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) p[i] += step;
+  }
+  __device__ __forceinline__ void store(char* img) const {
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) *reinterpret_cast<chunk16*>(img + loff[i]) = r[i];
+  }
+};
+
 // ------------------------------------------------------------------------------------------ forward
-template <typename T, int NW>
+// block = NW waves x 32 queries; K/V tiles of 64 keys double-buffered in LDS, the next tile is fetched into
+// registers while the current one is consumed (one barrier per tile).
+template <typename T, int NW, bool HAS_BIAS>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
   using C = ACfg<T>;
   constexpr int NT = 64 * NW;
-  __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES + 64 * 4];
-  char* Ks = smem;
-  char* Vs = smem + C::TILE_BYTES;
-  float* us = reinterpret_cast<float*>(smem + 2 * C::TILE_BYTES);
+  constexpr int BUF = 2 * C::TILE_BYTES + 64 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
   const int N = a.N, H = a.H;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -91,7 +140,6 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
   const T* kb = qb + H * 64;
   const T* vb = qb + 2 * H * 64;
   const int q0 = blockIdx.x * 32 * NW + wave * 32;
-  const bool has_bias = a.bias_u != nullptr;
 
   Frag<T> fq[2][2];
   float flagq[2];
@@ -100,7 +148,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
     const int q = q0 + qt * 16 + li;
 #pragma unroll
     for (int s = 0; s < 2; ++s) gload_frag<T>(fq[qt][s], qb + (long)q * ld + s * 32 + 8 * g, q < N);
-    flagq[qt] = (has_bias && a.row_flag && q < N) ? a.row_flag[(long)b * N + q] : 1.f;
+    flagq[qt] = (HAS_BIAS && a.row_flag && q < N) ? a.row_flag[(long)b * N + q] : 1.f;
   }
   float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
   f32x4 o[2][4];
@@ -109,15 +157,36 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < N; k0 += 64) {
-    __syncthreads();
-    load_tile64<T, NT>(Ks, kb, ld, k0, N);
-    load_tile64<T, NT>(Vs, vb, ld, k0, N);
-    if (threadIdx.x < 64) {
-      const int key = k0 + threadIdx.x;
-      us[threadIdx.x] = (has_bias && key < N) ? a.bias_w * a.bias_u[(long)b * N + key] : 0.f;
+  TilePF<T, NT> pk, pv;
+  pk.init(kb, ld);
+  pv.init(vb, ld);
+  float pu = 0.f;
+  const int ntile = (N + 63) / 64;
+  auto fetch = [&](int t) {
+    pk.load(t * 64, N);
+    pv.load(t * 64, N);
+    if (HAS_BIAS && threadIdx.x < 64) {
+      const int key = t * 64 + threadIdx.x;
+      pu = key < N ? a.bias_w * kLog2e * a.bias_u[(long)b * N + key] : 0.f;
     }
-    __syncthreads();
+  };
+  auto commit = [&](int buf) {
+    char* base = smem + buf * BUF;
+    pk.store(base);
+    pv.store(base + C::TILE_BYTES);
+    if (HAS_BIAS && threadIdx.x < 64) reinterpret_cast<float*>(base + 2 * C::TILE_BYTES)[threadIdx.x] = pu;
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntile; ++t) {
+    const int k0 = t * 64;
+    const char* Ks = smem + (t & 1) * BUF;
+    const char* Vs = Ks + C::TILE_BYTES;
+    const float* us = reinterpret_cast<const float*>(Ks + 2 * C::TILE_BYTES);
+    const bool more = t + 1 < ntile;
+    if (more) fetch(t + 1);
 
     f32x4 st[4][2];
 #pragma unroll
@@ -133,37 +202,48 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) st[ks][qt] = mma16(fk, fq[qt][s], st[ks][qt]);
       }
-    // scale + bias + key mask, running max
-    float mloc[2] = {-INFINITY, -INFINITY};
+    // Scores stay RAW (q.k) in the no-bias case: p = exp2(fma(raw, c, -m c)) with c = log2(e)/8 and m the running
+    // raw maximum (c > 0, so max commutes).  With the PASA bias they are moved to log2 units first.
+    const bool ragged = (k0 + 64 > N);
+    if (HAS_BIAS) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const f32x4 uu = *reinterpret_cast<const f32x4*>(us + ks * 16 + 4 * g);
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x4 uu = *reinterpret_cast<const f32x4*>(us + ks * 16 + 4 * g);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool kvalid = (k0 + ks * 16 + 4 * g + r) < N;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          float sv = st[ks][qt][r] * 0.125f + uu[r] * flagq[qt];
-          sv = kvalid ? sv : -INFINITY;
-          st[ks][qt][r] = sv;
-          mloc[qt] = fmaxf(mloc[qt], sv);
-        }
+          for (int qt = 0; qt < 2; ++qt) st[ks][qt][r] = fmaf(st[ks][qt][r], kScale2, uu[r] * flagq[qt]);
       }
     }
+    if (ragged) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((k0 + ks * 16 + 4 * g + r) >= N) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) st[ks][qt][r] = -INFINITY;
+          }
+    }
+    constexpr float kc = HAS_BIAS ? 1.f : kScale2;      // units of m / st relative to log2 units
     float alpha[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float mx = mloc[qt];
+      float mx = fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), fmaxf(st[0][qt][2], st[0][qt][3]));
+#pragma unroll
+      for (int ks = 1; ks < 4; ++ks)
+        mx = fmaxf(mx, fmaxf(fmaxf(st[ks][qt][0], st[ks][qt][1]), fmaxf(st[ks][qt][2], st[ks][qt][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(m[qt], mx);          // finite: every tile has >= 1 valid key
-      alpha[qt] = fexp<T>(m[qt] - mnew);            // m = -inf on the first tile -> 0
+      alpha[qt] = fexp2<T>((m[qt] - mnew) * kc);    // m = -inf on the first tile -> 0
+      const float mc = -mnew * kc;
       float ps = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = fexp<T>(st[ks][qt][r] - mnew);
+          const float p = fexp2<T>(fmaf(st[ks][qt][r], kc, mc));
           st[ks][qt][r] = p;
           ps += p;
         }
@@ -172,16 +252,17 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
       lsum[qt] = lsum[qt] * alpha[qt] + ps;
       m[qt] = mnew;
     }
-    // rescale O (rows of O are queries 4g + r -> fetch alpha from the lane that owns that query)
+    // rescale O only when some query of this wave moved its maximum (wave-uniform branch)
+    if (!__all(alpha[0] == 1.f && alpha[1] == 1.f)) {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+      for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float al = __shfl(alpha[qt], 4 * g + r, 64);
+        for (int r = 0; r < 4; ++r) {
+          const float al = __shfl(alpha[qt], 4 * g + r, 64);
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[qt][dt][r] *= al;
-      }
-    // O += P V
+          for (int dt = 0; dt < 4; ++dt) o[qt][dt][r] *= al;
+        }
+    }
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
       Frag<T> pa[2];
@@ -195,6 +276,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
         for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mma16(pa[qt], fv, o[qt][dt]);
       }
     }
+    if (more) commit((t + 1) & 1);
+    __syncthreads();
   }
 
   T* cb = reinterpret_cast<T*>(a.ctx) + (long)b * N * (H * 64) + h * 64;
@@ -211,7 +294,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
       }
     }
     const int q = q0 + qt * 16 + li;
-    if (g == 0 && q < N) a.lse[((long)b * H + h) * N + q] = m[qt] + logf(lsum[qt]);
+    if (g == 0 && q < N) a.lse[((long)b * H + h) * N + q] = m[qt] * ((HAS_BIAS ? 1.f : kScale2) * kLn2) + logf(lsum[qt]);
   }
 }
 
@@ -228,20 +311,25 @@ __global__ void attn_delta_kernel(const T* ctx, const T* dctx, float* delta, int
   const T* o = ctx + bq * (H * 64) + h * 64;
   const T* d = dctx + bq * (H * 64) + h * 64;
   float s = 0.f;
-#pragma unroll 8
-  for (int i = 0; i < 64; ++i) s += to_f32<T>(o[i]) * to_f32<T>(d[i]);
+  constexpr int EPC = 16 / sizeof(T);
+#pragma unroll
+  for (int i = 0; i < 64 / EPC; ++i) {
+    const chunk16 co = ld_global16(o + i * EPC), cd = ld_global16(d + i * EPC);
+    const T* po = reinterpret_cast<const T*>(&co);
+    const T* pd = reinterpret_cast<const T*>(&cd);
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) s += to_f32<T>(po[e]) * to_f32<T>(pd[e]);
+  }
   delta[((long)b * H + h) * N + q] = s;
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-template <typename T, int NW>
+template <typename T, int NW, bool HAS_BIAS>
 __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
   using C = ACfg<T>;
   constexpr int NT = 64 * NW;
-  __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES + 64 * 4];
-  char* Ks = smem;
-  char* Vs = smem + C::TILE_BYTES;
-  float* us = reinterpret_cast<float*>(smem + 2 * C::TILE_BYTES);
+  constexpr int BUF = 2 * C::TILE_BYTES + 64 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
   const int N = a.N, H = a.H;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -252,10 +340,9 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
   const T* vb = qb + 2 * H * 64;
   const T* dob = reinterpret_cast<const T*>(a.dctx) + (long)b * N * ldc + h * 64;
   const int q0 = blockIdx.x * 32 * NW + wave * 32;
-  const bool has_bias = a.bias_u != nullptr;
 
   Frag<T> fq[2][2], fdo[2][2];
-  float flagq[2], lseq[2], delq[2];
+  float flagq[2], lse2[2], delq[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int q = q0 + qt * 16 + li;
@@ -265,8 +352,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
       gload_frag<T>(fq[qt][s], qb + (long)q * ld + s * 32 + 8 * g, v);
       gload_frag<T>(fdo[qt][s], dob + (long)q * ldc + s * 32 + 8 * g, v);
     }
-    flagq[qt] = (has_bias && a.row_flag && v) ? a.row_flag[(long)b * N + q] : 1.f;
-    lseq[qt] = v ? a.lse[((long)b * H + h) * N + q] : 0.f;
+    flagq[qt] = (HAS_BIAS && a.row_flag && v) ? a.row_flag[(long)b * N + q] : 1.f;
+    lse2[qt] = v ? a.lse[((long)b * H + h) * N + q] * kLog2e : 0.f;
     delq[qt] = v ? a.delta[((long)b * H + h) * N + q] : 0.f;
   }
   f32x4 dq[2][4];
@@ -275,15 +362,36 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) dq[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int k0 = 0; k0 < N; k0 += 64) {
-    __syncthreads();
-    load_tile64<T, NT>(Ks, kb, ld, k0, N);
-    load_tile64<T, NT>(Vs, vb, ld, k0, N);
-    if (threadIdx.x < 64) {
-      const int key = k0 + threadIdx.x;
-      us[threadIdx.x] = (has_bias && key < N) ? a.bias_w * a.bias_u[(long)b * N + key] : 0.f;
+  TilePF<T, NT> pk, pv;
+  pk.init(kb, ld);
+  pv.init(vb, ld);
+  float pu = 0.f;
+  const int ntile = (N + 63) / 64;
+  auto fetch = [&](int t) {
+    pk.load(t * 64, N);
+    pv.load(t * 64, N);
+    if (HAS_BIAS && threadIdx.x < 64) {
+      const int key = t * 64 + threadIdx.x;
+      pu = key < N ? a.bias_w * kLog2e * a.bias_u[(long)b * N + key] : 0.f;
     }
-    __syncthreads();
+  };
+  auto commit = [&](int buf) {
+    char* base = smem + buf * BUF;
+    pk.store(base);
+    pv.store(base + C::TILE_BYTES);
+    if (HAS_BIAS && threadIdx.x < 64) reinterpret_cast<float*>(base + 2 * C::TILE_BYTES)[threadIdx.x] = pu;
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntile; ++t) {
+    const int k0 = t * 64;
+    const char* Ks = smem + (t & 1) * BUF;
+    const char* Vs = Ks + C::TILE_BYTES;
+    const float* us = reinterpret_cast<const float*>(Ks + 2 * C::TILE_BYTES);
+    const bool more = t + 1 < ntile;
+    if (more) fetch(t + 1);
 
     f32x4 st[4][2], dp[4][2];
 #pragma unroll
@@ -303,22 +411,31 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
           dp[ks][qt] = mma16(fv, fdo[qt][s], dp[ks][qt]);
         }
       }
-    // dS^T = P * (dP^T - delta)
+    const bool ragged = (k0 + 64 > N);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const f32x4 uu = *reinterpret_cast<const f32x4*>(us + ks * 16 + 4 * g);
+      f32x4 uu = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (HAS_BIAS) uu = *reinterpret_cast<const f32x4*>(us + ks * 16 + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool kvalid = (k0 + ks * 16 + 4 * g + r) < N;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          const float sv = st[ks][qt][r] * 0.125f + uu[r] * flagq[qt];
-          const float p = kvalid ? fexp<T>(sv - lseq[qt]) : 0.f;
-          st[ks][qt][r] = p * (dp[ks][qt][r] - delq[qt]);
+          const float e = HAS_BIAS ? fmaf(st[ks][qt][r], kScale2, uu[r] * flagq[qt]) - lse2[qt]
+                                   : fmaf(st[ks][qt][r], kScale2, -lse2[qt]);
+          st[ks][qt][r] = fexp2<T>(e) * (dp[ks][qt][r] - delq[qt]);
         }
       }
     }
-    // dQ += dS K
+    if (ragged) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((k0 + ks * 16 + 4 * g + r) >= N) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) st[ks][qt][r] = 0.f;
+          }
+    }
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
       Frag<T> pa[2];
@@ -332,6 +449,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
         for (int qt = 0; qt < 2; ++qt) dq[qt][dt] = mma16(pa[qt], fk, dq[qt][dt]);
       }
     }
+    if (more) commit((t + 1) & 1);
+    __syncthreads();
   }
   T* dqb = reinterpret_cast<T*>(a.dqkv) + (long)b * N * ld + h * 64;
 #pragma unroll
@@ -347,16 +466,12 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
-template <typename T, int NW>
+template <typename T, int NW, bool HAS_BIAS>
 __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
   using C = ACfg<T>;
   constexpr int NT = 64 * NW;
-  __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES + 3 * 64 * 4];
-  char* Qs = smem;
-  char* Ds = smem + C::TILE_BYTES;
-  float* lses = reinterpret_cast<float*>(smem + 2 * C::TILE_BYTES);
-  float* dels = lses + 64;
-  float* flgs = dels + 64;
+  constexpr int BUF = 2 * C::TILE_BYTES + 3 * 64 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
   const int N = a.N, H = a.H;
   const int b = blockIdx.z, h = blockIdx.y;
@@ -367,7 +482,6 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
   const T* vb = qb + 2 * H * 64;
   const T* dob = reinterpret_cast<const T*>(a.dctx) + (long)b * N * ldc + h * 64;
   const int key0 = blockIdx.x * 32 * NW + wave * 32;
-  const bool has_bias = a.bias_u != nullptr;
 
   Frag<T> fk[2][2], fv[2][2];
   float uk[2];
@@ -380,7 +494,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
       gload_frag<T>(fk[kt][s], kb + (long)key * ld + s * 32 + 8 * g, v);
       gload_frag<T>(fv[kt][s], vb + (long)key * ld + s * 32 + 8 * g, v);
     }
-    uk[kt] = (has_bias && v) ? a.bias_w * a.bias_u[(long)b * N + key] : 0.f;
+    uk[kt] = (HAS_BIAS && v) ? a.bias_w * kLog2e * a.bias_u[(long)b * N + key] : 0.f;
   }
   f32x4 dk[2][4], dv[2][4];
 #pragma unroll
@@ -388,22 +502,48 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[kt][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-  for (int q0 = 0; q0 < N; q0 += 64) {
-    __syncthreads();
-    load_tile64<T, NT>(Qs, qb, ld, q0, N);
-    load_tile64<T, NT>(Ds, dob, ldc, q0, N);
+  TilePF<T, NT> pq, pd;
+  pq.init(qb, ld);
+  pd.init(dob, ldc);
+  float ps3[3] = {0.f, 0.f, 1.f};
+  const int ntile = (N + 63) / 64;
+  auto fetch = [&](int t) {
+    pq.load(t * 64, N);
+    pd.load(t * 64, N);
     if (threadIdx.x < 64) {
-      const int q = q0 + threadIdx.x;
+      const int q = t * 64 + threadIdx.x;
       const bool v = q < N;
-      lses[threadIdx.x] = v ? a.lse[((long)b * H + h) * N + q] : 0.f;
-      dels[threadIdx.x] = v ? a.delta[((long)b * H + h) * N + q] : 0.f;
-      flgs[threadIdx.x] = (has_bias && a.row_flag && v) ? a.row_flag[(long)b * N + q] : 1.f;
+      ps3[0] = v ? a.lse[((long)b * H + h) * N + q] * kLog2e : 0.f;
+      ps3[1] = v ? a.delta[((long)b * H + h) * N + q] : 0.f;
+      ps3[2] = (HAS_BIAS && a.row_flag && v) ? a.row_flag[(long)b * N + q] : 1.f;
     }
-    __syncthreads();
+  };
+  auto commit = [&](int buf) {
+    char* base = smem + buf * BUF;
+    pq.store(base);
+    pd.store(base + C::TILE_BYTES);
+    if (threadIdx.x < 64) {
+      float* f = reinterpret_cast<float*>(base + 2 * C::TILE_BYTES);
+      f[threadIdx.x] = ps3[0]; f[64 + threadIdx.x] = ps3[1]; f[128 + threadIdx.x] = ps3[2];
+    }
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntile; ++t) {
+    const int q0 = t * 64;
+    const char* Qs = smem + (t & 1) * BUF;
+    const char* Ds = Qs + C::TILE_BYTES;
+    const float* lses = reinterpret_cast<const float*>(Qs + 2 * C::TILE_BYTES);
+    const float* dels = lses + 64;
+    const float* flgs = dels + 64;
+    const bool more = t + 1 < ntile;
+    if (more) fetch(t + 1);
+    const bool ragged = (q0 + 64 > N);
 
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
-      // S[q][key], dP[q][key] for the 32 queries of this macro step (2 sub-tiles), 32 keys of this wave
       f32x4 sc[2][2], dp[2][2];
 #pragma unroll
       for (int qs = 0; qs < 2; ++qs)
@@ -427,20 +567,27 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
         const int qo = ms * 32 + qs * 16 + 4 * g;
         const f32x4 ls = *reinterpret_cast<const f32x4*>(lses + qo);
         const f32x4 de = *reinterpret_cast<const f32x4*>(dels + qo);
-        const f32x4 fl = *reinterpret_cast<const f32x4*>(flgs + qo);
+        f32x4 fl = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (HAS_BIAS) fl = *reinterpret_cast<const f32x4*>(flgs + qo);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool qvalid = (q0 + qo + r) < N;
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
-            const float sv = sc[qs][kt][r] * 0.125f + uk[kt] * fl[r];
-            const float p = qvalid ? fexp<T>(sv - ls[r]) : 0.f;
+            const float e = HAS_BIAS ? fmaf(sc[qs][kt][r], kScale2, uk[kt] * fl[r]) - ls[r] : fmaf(sc[qs][kt][r], kScale2, -ls[r]);
+            const float p = fexp2<T>(e);
             sc[qs][kt][r] = p;
             dp[qs][kt][r] = p * (dp[qs][kt][r] - de[r]);
           }
         }
+        if (ragged) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((q0 + qo + r) >= N) {
+#pragma unroll
+              for (int kt = 0; kt < 2; ++kt) { sc[qs][kt][r] = 0.f; dp[qs][kt][r] = 0.f; }
+            }
+        }
       }
-      // dV[key][d] += sum_q P[q][key] dO[q][d] ;  dK[key][d] += sum_q dS[q][key] Q[q][d]
       Frag<T> pa[2], da[2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
@@ -459,6 +606,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
         }
       }
     }
+    if (more) commit((t + 1) & 1);
+    __syncthreads();
   }
   T* dkb = reinterpret_cast<T*>(a.dqkv) + (long)b * N * ld + H * 64 + h * 64;
   T* dvb = dkb + H * 64;
@@ -477,23 +626,37 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
     }
 }
 
-constexpr int kNW = 2;
-
-template <typename T>
+template <typename T, int NW>
 int fwd_launch(const AttnArgs& a, hipStream_t st) {
-  dim3 grid(ceil_div(a.N, 32 * kNW), a.H, a.B);
-  hipLaunchKernelGGL((attn_fwd_kernel<T, kNW>), grid, dim3(64 * kNW), 0, st, a);
+  dim3 grid(ceil_div(a.N, 32 * NW), a.H, a.B);
+  if (a.bias_u) hipLaunchKernelGGL((attn_fwd_kernel<T, NW, true>), grid, dim3(64 * NW), 0, st, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<T, NW, false>), grid, dim3(64 * NW), 0, st, a);
   return 0;
 }
-template <typename T>
+template <typename T, int NW>
 int bwd_launch(const AttnArgs& a, hipStream_t st) {
   const long total = (long)a.B * a.N * a.H;
   hipLaunchKernelGGL((attn_delta_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, st,
                      reinterpret_cast<const T*>(a.ctx), reinterpret_cast<const T*>(a.dctx), a.delta, a.B, a.N, a.H);
-  dim3 grid(ceil_div(a.N, 32 * kNW), a.H, a.B);
-  hipLaunchKernelGGL((attn_dq_kernel<T, kNW>), grid, dim3(64 * kNW), 0, st, a);
-  hipLaunchKernelGGL((attn_dkv_kernel<T, kNW>), grid, dim3(64 * kNW), 0, st, a);
+  dim3 grid(ceil_div(a.N, 32 * NW), a.H, a.B);
+  if (a.bias_u) {
+    hipLaunchKernelGGL((attn_dq_kernel<T, NW, true>), grid, dim3(64 * NW), 0, st, a);
+    hipLaunchKernelGGL((attn_dkv_kernel<T, NW, true>), grid, dim3(64 * NW), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((attn_dq_kernel<T, NW, false>), grid, dim3(64 * NW), 0, st, a);
+    hipLaunchKernelGGL((attn_dkv_kernel<T, NW, false>), grid, dim3(64 * NW), 0, st, a);
+  }
   return 0;
+}
+
+// waves per block: the environment variable S4F_ATTN_NW (2 | 3 | 4) overrides the default for experiments
+static int attn_nw() {
+  static int v = [] {
+    const char* e = getenv("S4F_ATTN_NW");
+    const int n = e ? atoi(e) : 4;
+    return (n == 2 || n == 3 || n == 4) ? n : 4;
+  }();
+  return v;
 }
 
 }  // namespace
@@ -507,7 +670,13 @@ S4F_API int s4f_attention_fwd(const void* qkv, void* ctx, float* lse, const floa
   AttnArgs a{};
   a.qkv = qkv; a.ctx = ctx; a.lse = lse; a.bias_u = bias_u; a.row_flag = row_flag; a.bias_w = bias_w;
   a.B = B; a.N = N; a.H = H;
-  if (dtype == S4F_BF16) fwd_launch<bf16_t>(a, (hipStream_t)stream); else fwd_launch<float>(a, (hipStream_t)stream);
+  const int nw = attn_nw();
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S4F_BF16) {
+    if (nw == 2) fwd_launch<bf16_t, 2>(a, st); else if (nw == 3) fwd_launch<bf16_t, 3>(a, st); else fwd_launch<bf16_t, 4>(a, st);
+  } else {
+    fwd_launch<float, 2>(a, st);
+  }
   S4F_LAUNCH_CHECK();
   return 0;
 }
@@ -521,7 +690,13 @@ S4F_API int s4f_attention_bwd(const void* qkv, const void* ctx, const void* dctx
   AttnArgs a{};
   a.qkv = qkv; a.ctx = const_cast<void*>(ctx); a.dctx = dctx; a.lse = const_cast<float*>(lse); a.delta = delta;
   a.dqkv = dqkv; a.bias_u = bias_u; a.row_flag = row_flag; a.bias_w = bias_w; a.B = B; a.N = N; a.H = H;
-  if (dtype == S4F_BF16) bwd_launch<bf16_t>(a, (hipStream_t)stream); else bwd_launch<float>(a, (hipStream_t)stream);
+  const int nw = attn_nw();
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == S4F_BF16) {
+    if (nw == 2) bwd_launch<bf16_t, 2>(a, st); else if (nw == 3) bwd_launch<bf16_t, 3>(a, st); else bwd_launch<bf16_t, 4>(a, st);
+  } else {
+    bwd_launch<float, 2>(a, st);
+  }
   S4F_LAUNCH_CHECK();
   return 0;
 }

@@ -20,6 +20,20 @@ if what == 'conv4':
     y = torch.empty(Mp, cout, device='cuda', dtype=T)
     def run():
         K.gemm(x, w, Mp, cout, 9 * cin, cin, 9 * cin, 1, a_mode=K.OP_ROW_CONV, out_t=y, ldo_t=cout, conv=(B, hw, hw, cin, 1), tile_hint=hint)
+elif what in ('attn', 'attnb'):
+    Bn, N, H = 16, 1025, 12
+    qkv = torch.randn(Bn, N, 3 * 768, device='cuda').to(T)
+    ctx = torch.empty(Bn, N, 768, device='cuda', dtype=T)
+    lse = torch.empty(Bn, H, N, device='cuda')
+    dctx = torch.randn(Bn, N, 768, device='cuda').to(T)
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty_like(lse)
+    K.attention_fwd(qkv, ctx, lse, Bn, N, H, 1)
+    def run():
+        if what == 'attn':
+            K.attention_fwd(qkv, ctx, lse, Bn, N, H, 1)
+        else:
+            K.attention_bwd(qkv, ctx, dctx, lse, delta, dqkv, Bn, N, H, 1)
 elif what == 'big':      # plain NT 8192^2 x 4096: no gather, no edge
     M, N, Kd = 8192, 8192, 4096
     x = torch.randn(M, Kd, device='cuda').to(T)
