@@ -206,6 +206,11 @@ def main():
             f['ms'] += d['ms']
             if name == 's4f_gemm':
                 f['gflop'] += d['calls'] * 2.0 * tag[2] * tag[3] * tag[4] / 1e9
+        shapes = {}
+        for (name, tag), d in summ.items():
+            if name == 's4f_gemm':
+                shapes[f'a{tag[0]}b{tag[1]} M={tag[2]} N={tag[3]} K={tag[4]}'] = dict(
+                    calls=d['calls'], ms=round(d['ms'], 3), tflops=round(d['calls'] * 2.0 * tag[2] * tag[3] * tag[4] / d['ms'] / 1e9, 1))
         total_ms = sum(f['ms'] for f in fam.values())
         kprof = {k: dict(calls=v['calls'], ms=round(v['ms'], 3), tflops=round(v['gflop'] / v['ms'], 1) if v['gflop'] else None)
                  for k, v in sorted(fam.items(), key=lambda kv: -kv[1]['ms'])}
@@ -236,7 +241,7 @@ def main():
         if kprof is not None:
             os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
             with open(os.path.join(ROOT, 'gpurun_out', f'bench_kernels_{args.workload}_{args.dtype}.json'), 'w') as f:
-                json.dump(kprof, f, indent=1)
+                json.dump(dict(families=kprof, gemm_shapes=dict(sorted(shapes.items(), key=lambda kv: -kv[1]['ms']))), f, indent=1)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

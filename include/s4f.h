@@ -47,8 +47,8 @@ int s4f_version(void);
 #define S4F_OP_K_CONV 4
 
 #define S4F_ACT_NONE 0
-#define S4F_ACT_GELU 1      /* out = gelu_erf(v); out_pre (if given) = v                      */
-#define S4F_ACT_GELU_BWD 2  /* out = v * gelu'(aux[m,n])                                       */
+#define S4F_ACT_GELU 1      /* out = gelu_erf(v); out_pre (if given) = gelu'(v)  (what the backward needs)   */
+#define S4F_ACT_GELU_BWD 2  /* out = v * aux[m,n]   (aux = the gelu'(.) tensor written by S4F_ACT_GELU)      */
 
 typedef struct s4f_gemm_desc {
   const void* A;

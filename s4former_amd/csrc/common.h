@@ -160,4 +160,26 @@ __device__ __forceinline__ void static_for_impl(F& f) {
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F f) { static_for_impl<0, N>(f); }
 
+// gelu(z) and gelu'(z) together.  EXACT: erff / expf (fp32 parity mode).  Otherwise Abramowitz-Stegun 7.1.26
+// (|erf error| < 1.5e-7, far below bf16 resolution) sharing one exp between the cdf and the pdf term.
+template <bool EXACT>
+__device__ __forceinline__ void gelu_pair(float z, float& y, float& dy) {
+  if constexpr (EXACT) {
+    y = gelu_f(z);
+    dy = gelu_grad_f(z);
+  } else {
+    const float x = fabsf(z) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-x * x * 1.4426950408889634f);           // exp(-z^2/2)
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f);
+    pl = fmaf(pl, t, -0.284496736f);
+    pl = fmaf(pl, t, 0.254829592f);
+    const float erfa = 1.0f - pl * t * e;                                              // erf(|x|)
+    const float cdf = 0.5f * (1.0f + copysignf(erfa, z));
+    y = z * cdf;
+    dy = fmaf(z * e, 0.39894228040143267794f, cdf);
+  }
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -94,25 +94,45 @@ __global__ void tokens_bwd_kernel(const float* __restrict__ dtok, float* __restr
 }
 
 // ---------------------------------------------------------------- column sums
-// block = 256 threads = 64 columns x 4 row lanes; grid.x = column blocks of 64, grid.y = row slabs
+// block = 256 threads = 32 column chunks (8 columns, one 16-B load of bf16 / two of fp32) x 8 row lanes;
+// grid.x = column blocks of 256, grid.y = row slabs.  ld must be a multiple of 8 elements.
 template <typename T>
-__global__ void colsum_kernel(const T* __restrict__ X, long ld, int M, int N, float* __restrict__ out, int rows_per_block,
-                              int skip_period) {
-  __shared__ float red[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int col = blockIdx.x * 64 + cx;
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, long ld, int M, int N, float* __restrict__ out,
+                                                     int rows_per_block, int skip_period) {
+  __shared__ float red[8][256 + 8];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+  const int col = blockIdx.x * 256 + cx * 8;
   const int r0 = blockIdx.y * rows_per_block;
   int r1 = r0 + rows_per_block;
   if (r1 > M) r1 = M;
-  float s = 0.f;
-  if (col < N)
-    for (int r = r0 + ry; r < r1; r += 4) {
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  if (col < N) {
+    for (int r = r0 + ry; r < r1; r += 8) {
       if (skip_period > 0 && (r % skip_period) == 0) continue;
-      s += to_f32<T>(X[(long)r * ld + col]);
+      const T* p = X + (long)r * ld + col;
+      if constexpr (sizeof(T) == 2) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+      } else {
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p), v1 = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s[e] += v0[e]; s[4 + e] += v1[e]; }
+      }
     }
-  red[ry][cx] = s;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ry][cx * 8 + e] = s[e];
   __syncthreads();
-  if (ry == 0 && col < N) atomicAdd(out + col, red[0][cx] + red[1][cx] + red[2][cx] + red[3][cx]);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < N) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    atomicAdd(out + c, t);
+  }
 }
 
 // ---------------------------------------------------------------- LayerNorm
@@ -380,8 +400,10 @@ S4F_API int s4f_tokens_bwd(const float* dtok, float* dpos, float* dcls, int B, i
 S4F_API int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int skip_period, int dtype, s4f_stream stream) {
   DT_CHECK("s4f_colsum");
   S4F_CHECK(X && out && M > 0 && N > 0 && ld >= N, "s4f_colsum: bad args");
-  const int rows_per_block = 128;
-  dim3 grid(ceil_div(N, 64), ceil_div(M, rows_per_block));
+  S4F_CHECK(ld % 8 == 0 && ((uintptr_t)X % 16) == 0, "s4f_colsum: ld must be a multiple of 8 elements, X 16-B aligned");
+  S4F_CHECK(((N + 7) / 8) * 8 <= ld, "s4f_colsum: the last 8-column chunk must lie inside the row (ld)");
+  const int rows_per_block = 512;
+  dim3 grid(ceil_div(N, 256), ceil_div(M, rows_per_block));
   if (dtype == S4F_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, (long)ld, M, N, out, rows_per_block, skip_period);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, (long)ld, M, N, out, rows_per_block, skip_period);
   S4F_LAUNCH_CHECK();

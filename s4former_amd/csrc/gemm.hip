@@ -275,10 +275,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs args) {
         const long orow = m;
         if (d.pos) v += d.pos[(long)(m % d.pos_period) * d.N + n];
         if (d.act == S4F_ACT_GELU) {
-          if (out_pre) out_pre[orow * d.ldo_pre + n] = from_f32<T>(v);
-          v = gelu_f(v);
+          float gy, gd;
+          gelu_pair<sizeof(T) == 4>(v, gy, gd);
+          if (out_pre) out_pre[orow * d.ldo_pre + n] = from_f32<T>(gd);
+          v = gy;
         } else if (d.act == S4F_ACT_GELU_BWD) {
-          v *= gelu_grad_f(to_f32<T>(aux[(long)m * d.ld_aux + n]));
+          v *= to_f32<T>(aux[(long)m * d.ld_aux + n]);
         }
         if (d.resid && first_split) v += d.resid[orow * d.ldr + n];
         if (d.out_f32) {

@@ -208,10 +208,12 @@ __device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, i
     float v = a[r] * d.alpha + bias;
     if (d.pos) v += d.pos[(long)(m % d.pos_period) * d.N + n];
     if (d.act == S4F_ACT_GELU) {
-      if (out_pre) out_pre[(long)m * d.ldo_pre + n] = (bf16_t)v;
-      v = gelu_f(v);
+      float gy, gd;
+      gelu_pair<false>(v, gy, gd);
+      if (out_pre) out_pre[(long)m * d.ldo_pre + n] = (bf16_t)gd;
+      v = gy;
     } else if (d.act == S4F_ACT_GELU_BWD) {
-      v *= gelu_grad_f((float)aux[(long)m * d.ld_aux + n]);
+      v *= (float)aux[(long)m * d.ld_aux + n];
     }
     if (d.resid && first_split) v += d.resid[(long)m * d.ldr + n];
     if (d.out_f32) {
@@ -377,18 +379,19 @@ __global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
           for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
         }
         if (d.act == S4F_ACT_GELU) {
-          if (out_pre) {
-            bf16x8 pv;
+          bf16x8 pv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pv[e] = (bf16_t)v[e];
-            *reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n) = pv;
+          for (int e = 0; e < 8; ++e) {
+            float gy, gd;
+            gelu_pair<false>(v[e], gy, gd);
+            v[e] = gy;
+            pv[e] = (bf16_t)gd;
           }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_f(v[e]);
+          if (out_pre) *reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n) = pv;
         } else if (d.act == S4F_ACT_GELU_BWD) {
           const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= gelu_grad_f((float)z[e]);
+          for (int e = 0; e < 8; ++e) v[e] *= (float)z[e];
         }
         if (d.resid && first_split) {
           const float* rp = d.resid + (long)m * d.ldr + n;

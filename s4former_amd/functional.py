@@ -29,6 +29,10 @@ def _splitk(tiles, nk, target=512):
     return int(max(1, min(sk, max(1, nk // 4))))
 
 
+def _tiles256(m, n):
+    return ((m + 255) // 256) * ((n + 255) // 256)
+
+
 def _tiles(m, n):
     return ((m + 127) // 128) * ((n + 127) // 128)
 
@@ -220,8 +224,15 @@ def head_forward(tokens, hp, store, training, save):
         Cc = cv['w'].shape[0]
         Mp = Bn * h * w
         y = torch.empty(Mp, Cc, device=dev, dtype=T)
-        K.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_t=y, ldo_t=Cc,
-               conv=(Bn, h, w, cin, 1))
+        if code == BF16 and _tiles256(Mp, Cc) < 96:
+            # few output tiles (the 32x32 stage): split the 9*cin contraction over blocks, fp32 partial sums
+            yf = torch.zeros(Mp, Cc, device=dev)
+            K.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_f32=yf,
+                   ldo_f32=Cc, atomic=True, splitk=max(2, min(16, 192 // _tiles256(Mp, Cc))), conv=(Bn, h, w, cin, 1))
+            K.cast(yf, y, code)
+        else:
+            K.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_t=y, ldo_t=Cc,
+                   conv=(Bn, h, w, cin, 1))
         scale = torch.empty(Cc, device=dev); shift = torch.empty(Cc, device=dev)
         mean = torch.empty(Cc, device=dev); rstd = torch.empty(Cc, device=dev)
         count = float(Mp) * world
@@ -292,8 +303,15 @@ def head_backward(dlo, dlo_t, sv, hp, store):
                splitk=_splitk(_tiles(Cc, 9 * cin_k), _nk(Mk, code), target=768), conv=(Bn, h, w, cin_k, 1))
         st['inp'] = None
         dcur = torch.empty(Mk, cin_k, device=dev, dtype=T)
-        K.gemm(dy, store.shadow(cv['w']), Mk, cin_k, 9 * Cc, Cc, 9 * cin_k, code, a_mode=K.OP_ROW_CONV, b_mode=K.OP_K_TAPSPLIT,
-               out_t=dcur, ldo_t=cin_k, conv=(Bn, h, w, Cc, -1))
+        if code == BF16 and _tiles256(Mk, cin_k) < 128:
+            df = torch.zeros(Mk, cin_k, device=dev)
+            K.gemm(dy, store.shadow(cv['w']), Mk, cin_k, 9 * Cc, Cc, 9 * cin_k, code, a_mode=K.OP_ROW_CONV,
+                   b_mode=K.OP_K_TAPSPLIT, out_f32=df, ldo_f32=cin_k, atomic=True,
+                   splitk=max(2, min(8, 256 // _tiles256(Mk, cin_k))), conv=(Bn, h, w, Cc, -1))
+            K.cast(df, dcur, code)
+        else:
+            K.gemm(dy, store.shadow(cv['w']), Mk, cin_k, 9 * Cc, Cc, 9 * cin_k, code, a_mode=K.OP_ROW_CONV,
+                   b_mode=K.OP_K_TAPSPLIT, out_t=dcur, ldo_t=cin_k, conv=(Bn, h, w, Cc, -1))
         del dy
     gh, gw = hp['grid']
     dtok = torch.zeros(Bn, ntok, E, device=dev)

@@ -80,7 +80,9 @@ def test_gemm_nt_gelu_resid(K, code):
     out_pre = torch.empty(M, N, device='cuda', dtype=tdt(code))
     K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), out_t=out_t, ldo_t=N, out_pre=out_pre,
            ldo_pre=N, act=K.ACT_GELU)
-    check(out_pre, z, code, 'gelu pre-activation')
+    zr_ = z.clone().requires_grad_(True)
+    O.gelu(zr_).sum().backward()
+    check(out_pre, zr_.grad, code, "gelu'(pre-activation)")
     check(out_t, a, code, 'gelu output')
     # residual epilogue: y = resid + x2 w2^T + b2
     M, N, K_ = 197, 768, 3072
@@ -95,13 +97,11 @@ def test_gemm_nt_gelu_resid(K, code):
 def test_gemm_gelu_bwd(K, code):
     M, N, K_ = 130, 3072, 768     # da = dy W2 (NN), dz = da * gelu'(z)
     dy, w2 = q(rnd(M, K_, seed=1), code), q(rnd(K_, N, seed=2, scale=0.05), code)   # w2 [768, 3072]
-    zz = q(rnd(M, N, seed=3, scale=2.0), code)
-    zr = zz.clone().requires_grad_(True)
-    O.gelu(zr).backward(dy @ w2)
+    gp = q(torch.rand(M, N, generator=torch.Generator().manual_seed(3)) * 1.2 - 0.1, code)    # a gelu'(z) tensor
     out_t = torch.empty(M, N, device='cuda', dtype=tdt(code))
-    K.gemm(dev(dy, code), dev(w2, code), M, N, K_, K_, N, code, b_mode=K.OP_K, out_t=out_t, ldo_t=N, aux=dev(zz, code),
+    K.gemm(dev(dy, code), dev(w2, code), M, N, K_, K_, N, code, b_mode=K.OP_K, out_t=out_t, ldo_t=N, aux=dev(gp, code),
            ld_aux=N, act=K.ACT_GELU_BWD)
-    check(out_t, zr.grad, code, 'gelu backward epilogue')
+    check(out_t, (dy @ w2) * gp, code, 'gelu backward epilogue (x gelu-prime tensor)')
 
 
 @pytest.mark.parametrize('code', DTYPES)
@@ -484,7 +484,9 @@ def test_gemm2_dense_modes(K, hint):
     K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), out_t=out_t, ldo_t=N, out_pre=out_pre, ldo_pre=N,
            act=K.ACT_GELU, tile_hint=hint)
     z = O.linear(x, w, b)
-    check(out_pre, z, code, 'gemm2 gelu pre'); check(out_t, O.gelu(z), code, 'gemm2 gelu out')
+    zr_ = z.clone().requires_grad_(True)
+    O.gelu(zr_).sum().backward()
+    check(out_pre, zr_.grad, code, "gemm2 gelu'"); check(out_t, O.gelu(z), code, 'gemm2 gelu out')
     # NN (B k-major): dx[M, K_] = dy[M, N] w[N, K_]
     dy = q(rnd(M, N, seed=5), code)
     dx = torch.empty(M, K_, device='cuda')
