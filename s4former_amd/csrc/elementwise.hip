@@ -402,8 +402,11 @@ S4F_API int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int 
   S4F_CHECK(X && out && M > 0 && N > 0 && ld >= N, "s4f_colsum: bad args");
   S4F_CHECK(ld % 8 == 0 && ((uintptr_t)X % 16) == 0, "s4f_colsum: ld must be a multiple of 8 elements, X 16-B aligned");
   S4F_CHECK(((N + 7) / 8) * 8 <= ld, "s4f_colsum: the last 8-column chunk must lie inside the row (ld)");
-  const int rows_per_block = 512;
-  dim3 grid(ceil_div(N, 256), ceil_div(M, rows_per_block));
+  const int nx = ceil_div(N, 256);
+  int rows_per_block = ceil_div((long)M * nx, 1536);
+  rows_per_block = ((rows_per_block + 7) / 8) * 8;
+  if (rows_per_block < 16) rows_per_block = 16;
+  dim3 grid(nx, ceil_div(M, rows_per_block));
   if (dtype == S4F_BF16) hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, (long)ld, M, N, out, rows_per_block, skip_period);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)X, (long)ld, M, N, out, rows_per_block, skip_period);
   S4F_LAUNCH_CHECK();

@@ -398,6 +398,98 @@ __global__ __launch_bounds__(256) void upce_bwd_kernel(const float* __restrict__
   }
 }
 
+// LDS-tiled variant for s = 2 | 4: a block owns TL x TL low-res pixels.  Phase 1 evaluates the softmax gradient of
+// every high-res pixel of the (TL s + 2 s)^2 window ONCE into LDS; phases 2a/2b apply the transposed bilinear stencil
+// separably (x, then y).  The gather kernel above recomputes each high-res softmax 16 (s=2) to 64 (s=4) times.
+template <typename T, int S, int TL>
+__global__ __launch_bounds__(256) void upce_bwd_tiled_kernel(const float* __restrict__ lo, const uint8_t* __restrict__ labels,
+                                                             float gscale, const float* __restrict__ gscale_dev,
+                                                             float* __restrict__ dlo, T* __restrict__ dlo_t, int B, int h, int w,
+                                                             int C, int ldc, int ignore) {
+  constexpr int HR = S * TL + 2 * S;
+  extern __shared__ float lds[];
+  float* G = lds;                          // [HR][HR][C]
+  float* tmp = lds + HR * HR * C;          // [HR][TL][C]
+  const int H = h * S, W = w * S;
+  const int tiles_x = (w + TL - 1) / TL, tiles_y = (h + TL - 1) / TL;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int ly0 = ty * TL, lx0 = tx * TL;
+  const int hy0 = S * ly0 - S, hx0 = S * lx0 - S;
+  if (gscale_dev) gscale *= *gscale_dev;
+  // phase 1
+  for (int i = threadIdx.x; i < HR * HR; i += 256) {
+    const int ry = i / HR, rx = i % HR;
+    const int oy = hy0 + ry, ox = hx0 + rx;
+    float* gp = G + i * C;
+    bool live = oy >= 0 && oy < H && ox >= 0 && ox < W;
+    int lab = 0;
+    if (live) {
+      lab = labels[((long)b * H + oy) * W + ox];
+      live = (lab != ignore) && lab < C;
+    }
+    if (!live) {
+      for (int c = 0; c < C; ++c) gp[c] = 0.f;
+      continue;
+    }
+    float z[kMaxC];
+    sample_logits(lo, b, oy, ox, h, w, C, ldc, S, z);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < C) mx = fmaxf(mx, z[c]);
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < C) { z[c] = expf(z[c] - mx); se += z[c]; }
+    const float inv = gscale / se;
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < C) gp[c] = z[c] * inv - ((c == lab) ? gscale : 0.f);
+  }
+  __syncthreads();
+  // phase 2a: along x
+  for (int i = threadIdx.x; i < HR * TL * C; i += 256) {
+    const int c = i % C;
+    const int t = i / C;
+    const int lxr = t % TL, ry = t / TL;
+    const int lx = lx0 + lxr;
+    float acc = 0.f;
+    if (lx < w) {
+      const int o0 = S * lx - S - hx0;            // first candidate column inside the window (= S * lxr)
+#pragma unroll
+      for (int k = 0; k < 3 * S; ++k) {
+        const int ox = hx0 + o0 + k;
+        if (ox >= 0 && ox < W) acc += lerp_w(ox, lx, S, w) * G[(ry * HR + o0 + k) * C + c];
+      }
+    }
+    tmp[i] = acc;
+  }
+  __syncthreads();
+  // phase 2b: along y, write out
+  for (int i = threadIdx.x; i < TL * TL * ldc; i += 256) {
+    const int c = i % ldc;
+    const int t = i / ldc;
+    const int lxr = t % TL, lyr = t / TL;
+    const int ly = ly0 + lyr, lx = lx0 + lxr;
+    if (ly >= h || lx >= w) continue;
+    float acc = 0.f;
+    if (c < C) {
+      const int o0 = S * lyr;
+#pragma unroll
+      for (int k = 0; k < 3 * S; ++k) {
+        const int oy = hy0 + o0 + k;
+        if (oy >= 0 && oy < H) acc += lerp_w(oy, ly, S, h) * tmp[((o0 + k) * TL + lxr) * C + c];
+      }
+    }
+    const long p = ((long)b * h + ly) * w + lx;
+    dlo[p * ldc + c] = acc;
+    if (dlo_t) dlo_t[p * ldc + c] = from_f32<T>(acc);
+  }
+}
+
 __global__ __launch_bounds__(256) void up_pseudo_kernel(const float* __restrict__ lo, uint8_t* __restrict__ label_out,
                                                         uint8_t* __restrict__ conf_out, unsigned long long* __restrict__ cnt,
                                                         float th, int B, int h, int w, int C, int ldc, int s) {
@@ -597,6 +689,22 @@ S4F_API int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, float gs
   DT_CHECK("s4f_upce_bwd");
   S4F_CHECK(logits_lo && labels && dlo, "s4f_upce_bwd: null pointer");
   LOGIT_CHECK("s4f_upce_bwd");
+  if (s == 2 || s == 4) {
+    const int TLv = s == 2 ? 8 : 4;
+    const int HR = s * TLv + 2 * s;
+    const size_t shm = (size_t)(HR * HR * C + HR * TLv * C) * sizeof(float);
+    const int nblk = B * ceil_div(h, TLv) * ceil_div(w, TLv);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S4F_BF16) {
+      if (s == 2) hipLaunchKernelGGL((upce_bwd_tiled_kernel<bf16_t, 2, 8>), dim3(nblk), dim3(256), shm, st, logits_lo, labels, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, ignore_index);
+      else hipLaunchKernelGGL((upce_bwd_tiled_kernel<bf16_t, 4, 4>), dim3(nblk), dim3(256), shm, st, logits_lo, labels, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, ignore_index);
+    } else {
+      if (s == 2) hipLaunchKernelGGL((upce_bwd_tiled_kernel<float, 2, 8>), dim3(nblk), dim3(256), shm, st, logits_lo, labels, gscale, gscale_dev, dlo, (float*)dlo_t, B, h, w, C, ldc, ignore_index);
+      else hipLaunchKernelGGL((upce_bwd_tiled_kernel<float, 4, 4>), dim3(nblk), dim3(256), shm, st, logits_lo, labels, gscale, gscale_dev, dlo, (float*)dlo_t, B, h, w, C, ldc, ignore_index);
+    }
+    S4F_LAUNCH_CHECK();
+    return 0;
+  }
   const long total = (long)B * h * w;
   const int grid = grid_for(total, 256);
   if (dtype == S4F_BF16) hipLaunchKernelGGL(upce_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, s, ignore_index);
