@@ -122,6 +122,7 @@ def main():
     import s4former_amd as S
     from s4former_amd import _lib
     from s4former_amd.dist import GradReducer, init_distributed
+    from s4former_amd.functional import join_side_streams
     from s4former_amd.presets import MAX_ITERS, OPTIMIZER, setr_pup_model, step_gflop, synthetic_batch
 
     rank, local, world = init_distributed()
@@ -159,6 +160,7 @@ def main():
         opt.zero_grad()
         out = model.train_step(dict(img=imgs, img_metas=metas, gt_semantic_seg=gt), opt, iter=it)
         out['loss'].backward()
+        join_side_streams()
         reducer.reduce_(model.student_store.grad)
         reducer.wait()
         opt.step(grad_scale=reducer.grad_scale())

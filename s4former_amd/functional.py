@@ -10,6 +10,8 @@ Reference semantics restated here:
                  pixels, Q5).  conv_seg is applied before the last bilinear upsample (they commute: both
                  linear, interpolation weights sum to 1) and the upsample is fused into the CE kernels.
 """
+import os
+
 import torch
 import torch.distributed as dist
 from torch.autograd import Function
@@ -18,6 +20,54 @@ from . import kernels as K
 from ._lib import BF16, F32, S4FError
 
 LOGIT_LD = 32   # channel stride of the low-resolution logits buffers (>= num_classes, multiple of 8)
+
+# ---------------------------------------------------------------------------------------------- side stream
+# Weight-gradient GEMMs and bias column sums do not feed the backward chain (they only accumulate into the gradient
+# arena), so they are enqueued on a second HIP stream: they fill the CUs that the tail of each chain kernel leaves
+# idle (tile-count quantisation: 768..1152 tiles over 256 CUs).  The optimiser / gradient reducer joins the stream.
+USE_SIDE_STREAM = os.environ.get('S4F_SIDE_STREAM', '1') != '0'
+_side = {}
+
+
+def side_stream(device):
+    key = torch.device(device).index
+    if key not in _side:
+        _side[key] = torch.cuda.Stream(device=device)
+    return _side[key]
+
+
+def join_side_streams():
+    """make the current stream wait for everything enqueued on the side stream(s)"""
+    cur = torch.cuda.current_stream()
+    for st in _side.values():
+        if st.device == cur.device:
+            cur.wait_stream(st)
+
+
+class on_side:
+    """with on_side(dev, t1, t2, ...): kernels launched inside run on the side stream after everything already enqueued
+    on the current stream; the tensors are kept alive for the side stream (caching-allocator record_stream)."""
+
+    def __init__(self, device, *tensors):
+        self.dev, self.tensors = device, tensors
+
+    def __enter__(self):
+        if not USE_SIDE_STREAM:
+            return self
+        self.side = side_stream(self.dev)
+        self.side.wait_stream(torch.cuda.current_stream())
+        self.ctx = torch.cuda.stream(self.side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if not USE_SIDE_STREAM:
+            return False
+        self.ctx.__exit__(*exc)
+        for t in self.tensors:
+            if t is not None:
+                t.record_stream(self.side)
+        return False
 
 
 def _T(code):
@@ -150,14 +200,16 @@ class LayerFn(Function):
         g2 = g2.contiguous()
         g2t = _as_T(g2, code)
         # ---- FFN
-        _wgrad(g2t, sv['a'], E, F_, M, E, F_, store.grad_phys(w2), code)
-        K.colsum(g2t, E, M, E, store.grad_phys(bf2), code)
+        with on_side(dev, g2t, sv['a']):
+            _wgrad(g2t, sv['a'], E, F_, M, E, F_, store.grad_phys(w2), code)
+            K.colsum(g2t, E, M, E, store.grad_phys(bf2), code)
         dz = torch.empty(M, F_, device=dev, dtype=T)
         K.gemm(g2t, store.shadow(w2), M, F_, E, E, F_, code, b_mode=K.OP_K, out_t=dz, ldo_t=F_, aux=sv['z'], ld_aux=F_,
                act=K.ACT_GELU_BWD)
         sv['z'] = sv['a'] = None
-        _wgrad(dz, sv['xn2'], F_, E, M, F_, E, store.grad_phys(w1), code)
-        K.colsum(dz, F_, M, F_, store.grad_phys(bf1), code)
+        with on_side(dev, dz, sv['xn2']):
+            _wgrad(dz, sv['xn2'], F_, E, M, F_, E, store.grad_phys(w1), code)
+            K.colsum(dz, F_, M, F_, store.grad_phys(bf1), code)
         dxn2 = torch.empty(M, E, device=dev, dtype=T)
         K.gemm(dz, store.shadow(w1), M, E, F_, F_, E, code, b_mode=K.OP_K, out_t=dxn2, ldo_t=E)
         del dz
@@ -168,16 +220,18 @@ class LayerFn(Function):
         if g1t is None:
             g1t = g1
         # ---- attention
-        _wgrad(g1t, sv['ctxv'], E, E, M, E, E, store.grad_phys(wo), code)
-        K.colsum(g1t, E, M, E, store.grad_phys(bo), code)
+        with on_side(dev, g1t, sv['ctxv']):
+            _wgrad(g1t, sv['ctxv'], E, E, M, E, E, store.grad_phys(wo), code)
+            K.colsum(g1t, E, M, E, store.grad_phys(bo), code)
         dctx = torch.empty(M, E, device=dev, dtype=T)
         K.gemm(g1t, store.shadow(wo), M, E, E, E, E, code, b_mode=K.OP_K, out_t=dctx, ldo_t=E)
         dqkv = torch.empty(M, 3 * E, device=dev, dtype=T)
         delta = torch.empty(Bn, H, N, device=dev)
         K.attention_bwd(sv['qkv'], sv['ctxv'], dctx, sv['lse'], delta, dqkv, Bn, N, H, code, bias_u=sv['bias_u'],
                         row_flag=sv['row_flag'], bias_w=bias_w)
-        _wgrad(dqkv, sv['xn'], 3 * E, E, M, 3 * E, E, store.grad_phys(wqkv), code)
-        K.colsum(dqkv, 3 * E, M, 3 * E, store.grad_phys(bqkv), code)
+        with on_side(dev, dqkv, sv['xn']):
+            _wgrad(dqkv, sv['xn'], 3 * E, E, M, 3 * E, E, store.grad_phys(wqkv), code)
+            K.colsum(dqkv, 3 * E, M, 3 * E, store.grad_phys(bqkv), code)
         dxn = torch.empty(M, E, device=dev, dtype=T)
         K.gemm(dqkv, store.shadow(wqkv), M, E, 3 * E, 3 * E, E, code, b_mode=K.OP_K, out_t=dxn, ldo_t=E)
         del dqkv
@@ -298,9 +352,10 @@ def head_backward(dlo, dlo_t, sv, hp, store):
         del g
         st['y'] = None
         # conv weight gradient [Cc][3][3][cin] += dy^T (shifted inp)
-        K.gemm(dy, st['inp'], Cc, 9 * cin_k, Mk, Cc, cin_k, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV,
-               out_f32=store.grad_phys(cv['w']), ldo_f32=9 * cin_k, atomic=True,
-               splitk=_splitk(_tiles(Cc, 9 * cin_k), _nk(Mk, code), target=768), conv=(Bn, h, w, cin_k, 1))
+        with on_side(dev, dy, st['inp']):
+            K.gemm(dy, st['inp'], Cc, 9 * cin_k, Mk, Cc, cin_k, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV,
+                   out_f32=store.grad_phys(cv['w']), ldo_f32=9 * cin_k, atomic=True,
+                   splitk=_splitk(_tiles(Cc, 9 * cin_k), _nk(Mk, code), target=768), conv=(Bn, h, w, cin_k, 1))
         st['inp'] = None
         dcur = torch.empty(Mk, cin_k, device=dev, dtype=T)
         if code == BF16 and _tiles256(Mk, cin_k) < 128:

@@ -49,6 +49,8 @@ class S4FSGD(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
         loss = closure() if closure is not None else None
+        from .functional import join_side_streams
+        join_side_streams()          # weight-gradient kernels run on a side stream
         store, plan = self._plan()
         first = store.first_sgd_step
         for gname, a, b, idx in plan:

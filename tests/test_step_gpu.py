@@ -44,7 +44,7 @@ def run_product(model, opt, sched, meta, iters=2):
         opt.zero_grad()
         out = model.train_step(dict(img=imgs.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda()), opt, iter=it)
         out['loss'].backward()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()        # (also joins the side stream: device-wide)
         gn = {n: float(p.grad.norm()) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
         rec.append(dict(log=out['log_vars'], gn=gn))
         opt.step()
