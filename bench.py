@@ -128,8 +128,9 @@ def main():
     rank, local, world = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback on the product path)'
-    torch.cuda.set_device(local)
-    dev = torch.device('cuda', local)
+    local_dev = local % torch.cuda.device_count()      # (gloo smoke runs may put several ranks on one GPU)
+    torch.cuda.set_device(local_dev)
+    dev = torch.device('cuda', local_dev)
     S.set_compute_dtype(args.dtype)
 
     n_sup, n_unsup, img, ncls, flags, desc = WORKLOADS[args.workload]
@@ -149,6 +150,7 @@ def main():
     if model.teacher_store is not None:
         reducer.broadcast_(model.teacher_store.flat)
     model.student_store.mark_dirty()
+    reducer.attach(model.student_store)
 
     seg_gain = 1.0
     if n_unsup and rank == 0 or (n_unsup and world > 1):

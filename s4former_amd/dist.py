@@ -19,9 +19,9 @@ def init_distributed(backend=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
+            backend = os.environ.get('S4F_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -33,35 +33,75 @@ def world_size():
 
 
 class GradReducer:
-    """Sum-all-reduce of the gradient arena in `bucket_mb` chunks (the division by world is applied by the optimiser:
-    S4FSGD.step(grad_scale=1/world)).  Works on any flat tensor, so it is covered by gloo tests on CPU."""
+    """Sum-all-reduce of the gradient arena (the division by world is applied by the optimiser:
+    S4FSGD.step(grad_scale=1/world)).
+
+    attach(store): overlap with backward.  Every encoder layer reports its arena range as soon as its backward node
+    has run (ParamStore.range_done); that bucket (7.1 M fp32 = 28 MB, one contiguous range) is all-reduced at once on
+    a communication stream while the earlier layers are still computing.  reduce_() then covers what is left (heads,
+    patch embedding) in `bucket_mb` chunks.  Backward visits the layers in the same order on every rank, so the
+    collectives line up.  Works on any flat tensor / backend, so it is covered by gloo tests on CPU."""
 
     def __init__(self, bucket_mb=128, side_stream=True):
         self.bucket = int(bucket_mb * 1024 * 1024 // 4)
         self.side_stream = side_stream
         self._stream = None
         self._handles = []
+        self._done = []          # ranges already launched in this step
+        self._store = None
+
+    def attach(self, store):
+        self._store = store
+        store.on_range_done = self._range_done
+        return self
 
     def broadcast_(self, flat, src=0):
         if world_size() > 1:
             dist.broadcast(flat, src=src)
 
+    def _comm_ctx(self, t):
+        use_side = self.side_stream and t.is_cuda
+        if not use_side:
+            return _Null()
+        if self._stream is None:
+            self._stream = torch.cuda.Stream()
+        self._stream.wait_stream(torch.cuda.current_stream())
+        try:
+            from .functional import _side
+            for st in _side.values():
+                self._stream.wait_stream(st)          # weight-gradient kernels run on the compute side stream
+        except ImportError:
+            pass
+        return torch.cuda.stream(self._stream)
+
+    def _launch(self, t):
+        with self._comm_ctx(t):
+            self._handles.append(dist.all_reduce(t, async_op=True))
+
+    def _range_done(self, a, b):
+        if world_size() == 1 or self._store is None or self._store.grad is None:
+            return
+        self._launch(self._store.grad[a:b])
+        self._done.append((a, b))
+
     def reduce_(self, flat_grad):
-        """launch the all-reduces; call wait() before the optimiser step"""
+        """launch the all-reduces of every range not yet reduced in this step; call wait() before the optimiser step"""
         if world_size() == 1:
+            self._done = []
             return
         n = flat_grad.numel()
-        use_side = self.side_stream and flat_grad.is_cuda
-        if use_side:
-            if self._stream is None:
-                self._stream = torch.cuda.Stream()
-            self._stream.wait_stream(torch.cuda.current_stream())
-            ctx = torch.cuda.stream(self._stream)
-        else:
-            ctx = _Null()
-        with ctx:
-            for a in range(0, n, self.bucket):
-                self._handles.append(dist.all_reduce(flat_grad[a:min(n, a + self.bucket)], async_op=True))
+        pos = 0
+        gaps = []
+        for a, b in sorted(self._done):
+            if a > pos:
+                gaps.append((pos, a))
+            pos = max(pos, b)
+        if pos < n:
+            gaps.append((pos, n))
+        for a, b in gaps:
+            for c in range(a, b, self.bucket):
+                self._launch(flat_grad[c:min(b, c + self.bucket)])
+        self._done = []
 
     def wait(self):
         for h in self._handles:

@@ -182,6 +182,7 @@ class LayerFn(Function):
         K.gemm(a, store.shadow(w2), M, E, F_, F_, F_, code, bias=store.phys(bf2), resid=x1, ldr=E, out_f32=x2, ldo_f32=E)
         if any(ctx.needs_input_grad):
             ctx.store, ctx.prm = store, prm
+            ctx.range = store.range_of(prm)
             ctx.cfg = (Bn, N, E, F_, num_heads, bias_w)
             ctx.sv = dict(x=x, xn=xn, mean1=mean1, rstd1=rstd1, qkv=qkv, ctxv=ctxv, lse=lse, x1=x1, xn2=xn2, mean2=mean2,
                           rstd2=rstd2, z=z, a=a, bias_u=bias_u, row_flag=row_flag)
@@ -245,6 +246,7 @@ class LayerFn(Function):
             g0._s4f_t = (g0t, g0._version, g0.data_ptr())
         ctx.sv = None
         store.node_done()
+        store.range_done(*ctx.range)
         return (g0,) + (None,) * (6 + 12)
 
 

@@ -197,6 +197,20 @@ class ParamStore:
         if cb is not None:
             cb()
 
+    def range_of(self, tensors):
+        """[a, b) arena range spanned by the given parameters (padded to the arena alignment)"""
+        es = [self.entry(t) for t in tensors]
+        a = min(e.off for e in es)
+        b = max(e.off + (e.numel + ALIGN - 1) // ALIGN * ALIGN for e in es)
+        return a, b
+
+    def range_done(self, a, b):
+        """the gradients of arena range [a, b) are final for this step (called at the end of a node's backward);
+        the data-parallel reducer hooks in here to start that bucket's all-reduce while backward continues"""
+        cb = getattr(self, 'on_range_done', None)
+        if cb is not None:
+            cb(a, b)
+
     def zero_grad(self):
         if self.grad is not None:
             self.grad.zero_()

@@ -31,6 +31,17 @@ def _worker(rank, world, port, q):
     red.reduce_(grad)
     red.wait()
     res['grad'] = (grad * red.grad_scale()).clone()
+    # 1b. overlapped buckets: ranges reported during "backward", the rest in reduce_()
+    class FakeStore:
+        pass
+    st = FakeStore()
+    st.grad = torch.randn(300_001, generator=torch.Generator().manual_seed(200 + rank))
+    red2 = GradReducer(bucket_mb=0.25, side_stream=False).attach(st)
+    st.on_range_done(200_000, 260_000)
+    st.on_range_done(100_000, 200_000)
+    red2.reduce_(st.grad)
+    red2.wait()
+    res['grad2'] = (st.grad * red2.grad_scale()).clone()
     # 2. parameters broadcast from rank 0
     p = torch.full((1000,), float(rank))
     red.broadcast_(p, src=0)
@@ -74,6 +85,9 @@ def test_world2_gloo():
     g1 = torch.randn(300_001, generator=torch.Generator().manual_seed(101))
     ref = (g0 + g1) / 2
     assert torch.allclose(out[0]['grad'], ref, atol=1e-6) and torch.equal(out[0]['grad'], out[1]['grad'])
+    h0 = torch.randn(300_001, generator=torch.Generator().manual_seed(200))
+    h1 = torch.randn(300_001, generator=torch.Generator().manual_seed(201))
+    assert torch.allclose(out[0]['grad2'], (h0 + h1) / 2, atol=1e-6) and torch.equal(out[0]['grad2'], out[1]['grad2'])
     assert out[0]['bcast'] == 0.0 and out[1]['bcast'] == 0.0
     # local loss stays local (it is what backward runs on); logged values are the rank mean
     assert out[0]['loss_local'] == 1.5 and out[1]['loss_local'] == 3.0
