@@ -274,6 +274,57 @@ __global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  auto load_frags = [&](Frag<bf16_t> (&a)[4], Frag<bf16_t> (&b)[NJ], const char* As, const char* Bs, int s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (AK) frag_k<BM>(a[i], As, wm * 64 + i * 16, s);
+      else frag_row<TRMAP>(a[i], As, wm * 64 + i * 16, s);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      if constexpr (BKM) frag_k<BN>(b[j], Bs, wn * WTN + j * 16, s);
+      else frag_row<TRMAP>(b[j], Bs, wn * WTN + j * 16, s);
+    }
+  };
+  auto mma_all = [&](const Frag<bf16_t> (&a)[4], const Frag<bf16_t> (&b)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(a[i], b[j], acc[i][j]);
+  };
+
+  if constexpr (NW == 8 && BN == 128) {
+    // Software-pipelined loop (2 waves per SIMD): the fragments of the second 32-deep step are read while the first
+    // step's MFMAs run, and their MFMAs are issued AFTER the barrier, under the LDS reads of the next tile's first
+    // step and the DMA issue — the MFMA pipe has work on both sides of every barrier.
+    Frag<bf16_t> a0[4], b0[NJ], a1[4], b1[NJ];
+    if (kt_beg < kt_end) {
+      if (kt_beg + 1 < kt_end) {
+        fa.issue(kt_beg + 1, smem + STAGE);
+        fb.issue(kt_beg + 1, smem + STAGE + A_BYTES);
+      }
+      load_frags(a0, b0, smem, smem + A_BYTES, 0);
+    }
+    for (int kt = kt_beg; kt < kt_end; ++kt) {
+      const int cur = (kt - kt_beg) & 1;
+      char* As = smem + cur * STAGE;
+      char* Bs = As + A_BYTES;
+      char* An = smem + (cur ^ 1) * STAGE;
+      load_frags(a1, b1, As, Bs, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own reads of this buffer + own DMA of the next tile
+      __syncthreads();
+      if (kt + 2 < kt_end) {
+        fa.issue(kt + 2, As);
+        fb.issue(kt + 2, Bs);
+      }
+      if (kt + 1 < kt_end) load_frags(a0, b0, An, An + A_BYTES, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_all(a1, b1);
+    }
+  } else {
   for (int kt = kt_beg; kt < kt_end; ++kt) {
     const int cur = (kt - kt_beg) & 1;
     char* As = smem + cur * STAGE;
@@ -285,24 +336,14 @@ __global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
     for (int s = 0; s < 2; ++s) {
       if (s == 1 && more) fb.issue(kt + 1, An + A_BYTES);
       Frag<bf16_t> a[4], b[NJ];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (AK) frag_k<BM>(a[i], As, wm * 64 + i * 16, s);
-        else frag_row<TRMAP>(a[i], As, wm * 64 + i * 16, s);
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        if constexpr (BKM) frag_k<BN>(b[j], Bs, wn * WTN + j * 16, s);
-        else frag_row<TRMAP>(b[j], Bs, wn * WTN + j * 16, s);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = mma16(a[i], b[j], acc[i][j]);
+      load_frags(a, b, As, Bs, s);
+      mma_all(a, b);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  }
+  __syncthreads();
 
   // ------------------------------------------------------------------ epilogue (same contract as gemm.hip)
   const bool first_split = (blockIdx.z == 0);
