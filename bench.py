@@ -222,9 +222,16 @@ def main():
         gemm_gflop = sum(v['gflop'] for k, v in fam.items() if k.startswith('s4f_gemm'))
         gemm_calls = sum(v['calls'] for k, v in fam.items() if k.startswith('s4f_gemm'))
         peak = MFMA_PEAK_TFLOPS[args.dtype]
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_gemm_hbm_traffic.json')
+        if args.workload == 'semi' and args.dtype == 'bf16' and os.path.exists(tpath):
+            # HBM bytes per GEMM launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command
+            # (separate --pmc runs, FETCH_SIZE doubled for gfx950); bench.py cannot run the profiler on itself.
+            traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
         roofline = dict(bound='mfma', kernel='gemm_kernel<T, AMODE, BMODE> (dense + implicit-GEMM conv family)',
                         achieved=round(gemm_gflop / gemm_ms, 1), peak=peak, unit='TFLOP/s',
-                        frac=round(gemm_gflop / gemm_ms / peak, 4), traffic=None,
+                        frac=round(gemm_gflop / gemm_ms / peak, 4), traffic=traffic,
+                        algorithmic_gflop_per_launch=round(gemm_gflop / gemm_calls, 2),
                         launches_per_step=gemm_calls, avg_launch_ms=round(gemm_ms / gemm_calls, 4),
                         share_of_step_kernel_time=round(gemm_ms / total_ms, 3),
                         step=dict(achieved=round(step_tflops, 1), frac=round(step_tflops / peak, 4),

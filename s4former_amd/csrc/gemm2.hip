@@ -247,7 +247,17 @@ __global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
     const int basei = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     L = basei + (L >> 3);
   }
-  const int tm = L / args.tiles_n, tn = L - tm * args.tiles_n;
+  // grouped order inside the XCD's contiguous range: 8 tile-rows x all tile-columns per group, rows fastest, so that
+  // the ~32 tiles in flight on one XCD (32 CUs) share 8 A panels and 4 B panels in its 4 MiB L2
+  int tm, tn;
+  {
+    constexpr int GM = 8;
+    const int per_group = GM * args.tiles_n;
+    const int grp = L / per_group, r = L - grp * per_group;
+    const int rows_here = min(GM, args.tiles_m - grp * GM);
+    tm = grp * GM + r % rows_here;
+    tn = r / rows_here;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
   const int kt_beg = blockIdx.z * args.nk_per_split;
   int kt_end = kt_beg + args.nk_per_split;
