@@ -189,10 +189,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
     if (more) fetch(t + 1);
 
     f32x4 st[4][2];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) st[ks][qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -200,7 +197,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
         Frag<T> fk;
         tile_rowfrag<T>(fk, Ks, ks * 16 + li, s);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) st[ks][qt] = mma16(fk, fq[qt][s], st[ks][qt]);
+        for (int qt = 0; qt < 2; ++qt) st[ks][qt] = mma16(fk, fq[qt][s], s == 0 ? zero4 : st[ks][qt]);
       }
     // Scores stay RAW (q.k) in the no-bias case: p = exp2(fma(raw, c, -m c)) with c = log2(e)/8 and m the running
     // raw maximum (c > 0, so max commutes).  With the PASA bias they are moved to log2 units first.
@@ -235,7 +232,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
         mx = fmaxf(mx, fmaxf(fmaxf(st[ks][qt][0], st[ks][qt][1]), fmaxf(st[ks][qt][2], st[ks][qt][3])));
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float mnew = fmaxf(m[qt], mx);          // finite: every tile has >= 1 valid key
+      // bf16 mode: keep the old maximum while the new one exceeds it by < 2^kDefer (P stays <= 2^kDefer, harmless for
+      // the fp32 accumulators and bf16 P operands); the O / l rescale then happens only when the maximum really moves.
+      // fp32 parity mode: exact running maximum.
+      constexpr float kDefer = sizeof(T) == 2 ? 6.0f : 0.0f;
+      float mnew = fmaxf(m[qt], mx);                // finite: every tile has >= 1 valid key
+      if (kDefer > 0.f && (mnew - m[qt]) * kc <= kDefer) mnew = m[qt];
       alpha[qt] = fexp2<T>((m[qt] - mnew) * kc);    // m = -inf on the first tile -> 0
       const float mc = -mnew * kc;
       float ps = 0.f;
@@ -394,10 +396,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
     if (more) fetch(t + 1);
 
     f32x4 st[4][2], dp[4][2];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int qt = 0; qt < 2; ++qt) { st[ks][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[ks][qt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -407,8 +406,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
         tile_rowfrag<T>(fv, Vs, ks * 16 + li, s);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          st[ks][qt] = mma16(fk, fq[qt][s], st[ks][qt]);
-          dp[ks][qt] = mma16(fv, fdo[qt][s], dp[ks][qt]);
+          st[ks][qt] = mma16(fk, fq[qt][s], s == 0 ? zero4 : st[ks][qt]);
+          dp[ks][qt] = mma16(fv, fdo[qt][s], s == 0 ? zero4 : dp[ks][qt]);
         }
       }
     const bool ragged = (k0 + 64 > N);
@@ -545,10 +544,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
       f32x4 sc[2][2], dp[2][2];
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs)
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) { sc[qs][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qs][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -558,8 +554,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
           tile_rowfrag<T>(fdr, Ds, ms * 32 + qs * 16 + li, s);
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
-            sc[qs][kt] = mma16(fqr, fk[kt][s], sc[qs][kt]);
-            dp[qs][kt] = mma16(fdr, fv[kt][s], dp[qs][kt]);
+            sc[qs][kt] = mma16(fqr, fk[kt][s], s == 0 ? zero4 : sc[qs][kt]);
+            dp[qs][kt] = mma16(fdr, fv[kt][s], s == 0 ? zero4 : dp[qs][kt]);
           }
         }
 #pragma unroll
