@@ -79,7 +79,8 @@ typedef struct s4f_gemm_desc {
   int32_t pos_period;
   const float* pos;         /* fp32 [pos_period, N] or NULL */
   /* kernel selection: 0 = automatic; 1 = 128x128 register-staged kernel; 2 = 256x128 LDS-DMA kernel;
-   * 3 = 256x256 LDS-DMA kernel, 8 waves; 4 = 256x256, 16 waves (2-4: bf16 only) */
+   * 3 = 256x256 LDS-DMA kernel, 8 waves; 4 = 256x256, 16 waves; 5 = 256x256, 16 waves, K step 32, 4-stage ring
+   * with counted waits (2-5: bf16 only) */
   int32_t tile_hint;
 } s4f_gemm_desc;
 

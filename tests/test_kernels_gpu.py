@@ -469,7 +469,7 @@ def test_ema_sgd(K, code):
 
 
 # ------------------------------------------------------------------------------------------------ 256-row LDS-DMA kernel
-@pytest.mark.parametrize('hint', [2, 3, 4])
+@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6])
 def test_gemm2_dense_modes(K, hint):
     code = 1
     M, N, K_ = 1000, 768, 832
@@ -506,7 +506,7 @@ def test_gemm2_dense_modes(K, hint):
     assert float(o21[:, 21:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('hint', [2, 3, 4])
+@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6])
 @pytest.mark.parametrize('Cin,Cout', [(768, 256), (256, 256)])
 def test_gemm2_conv_modes(K, hint, Cin, Cout):
     code = 1

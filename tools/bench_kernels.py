@@ -41,7 +41,7 @@ def report(name, ms, flops=None, bytes_=None):
 
 B, N, C = int(os.environ.get("BENCH_B", "8")), 1025, 768
 M = B * N
-HINTS = (1, 2, 3, 4) if code else (1,)
+HINTS = (1, 2, 3, 4, 5) if code else (1,)
 for (n, k, nm) in [(2304, 768, 'qkv'), (768, 768, 'proj'), (3072, 768, 'fc1'), (768, 3072, 'fc2')]:
     x, w = rt(M, k), rt(n, k, scale=0.02)
     out = torch.empty(M, n, device=dev, dtype=T)

@@ -41,6 +41,20 @@ elif what == 'big':      # plain NT 8192^2 x 4096: no gather, no edge
     y = torch.empty(M, N, device='cuda', dtype=T)
     def run():
         K.gemm(x, w, M, N, Kd, Kd, Kd, 1, out_t=y, ldo_t=N, tile_hint=hint)
+elif what.startswith('tn'):      # tn:M:N:rows:splitk   dW[M,N] += dy[rows,M]^T x[rows,N]
+    _, M, N, R, sk = what.split(':'); M, N, R, sk = int(M), int(N), int(R), int(sk)
+    dy = torch.randn(R, M, device='cuda').to(T)
+    x = torch.randn(R, N, device='cuda').to(T)
+    dw = torch.zeros(M, N, device='cuda')
+    def run():
+        K.gemm(dy, x, M, N, R, M, N, 1, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=dw, ldo_f32=N, atomic=True, splitk=sk, tile_hint=hint)
+elif what.startswith('nt'):      # nt:M:N:K
+    _, M, N, Kd = what.split(':'); M, N, Kd = int(M), int(N), int(Kd)
+    x = torch.randn(M, Kd, device='cuda').to(T)
+    w = (torch.randn(N, Kd, device='cuda') * 0.02).to(T)
+    y = torch.empty(M, N, device='cuda', dtype=T)
+    def run():
+        K.gemm(x, w, M, N, Kd, Kd, Kd, 1, out_t=y, ldo_t=N, tile_hint=hint)
 else:
     M, N, Kd = 8200, 3072, 768
     x = torch.randn(M, Kd, device='cuda').to(T)
