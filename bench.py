@@ -179,6 +179,7 @@ def main():
     for _ in range(args.steps):
         out = step(it)
         it += 1
+    host_dt = time.perf_counter() - t0             # time the host needed to enqueue the K steps (no sync inside)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -248,7 +249,8 @@ def main():
                     config=dict(workload=f'{args.workload}: {desc}', images_per_step_per_gpu=n_sup + n_unsup,
                                 crop=f'{img}x{img}', classes=ncls, parallelism=f'dp{world}', weights='random-init DeiT-B',
                                 teacher_conv_seg_gain=round(seg_gain, 2)),
-                    roofline=roofline, cpu_baseline=cpu, losses=losses, mask_ratio=mask_ratio)
+                    roofline=roofline, cpu_baseline=cpu, losses=losses, mask_ratio=mask_ratio,
+                    host_enqueue_ms_per_step=round(1e3 * host_dt / args.steps, 3))
         if kprof is not None:
             os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
             with open(os.path.join(ROOT, 'gpurun_out', f'bench_kernels_{args.workload}_{args.dtype}.json'), 'w') as f:

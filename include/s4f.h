@@ -169,11 +169,14 @@ int s4f_bn_param_grads(const float* sums_local, float* dgamma, float* dbeta, int
  *   loss_sum += sum_pixels [label != ignore] (logsumexp(z) - z[label])        (fp32 atomic, caller divides)
  *   dlogits_hi T/fp32 is not materialised: dlo fp32 [B,h,w,ldc] += up_s^T( gscale * (softmax(z) - onehot) )
  * labels: uint8 [B, h*s, w*s] (255 = ignore). Two launches: fwd (loss), bwd (dlo, recomputes softmax). */
-int s4f_upce_fwd(const float* logits_lo, const uint8_t* labels, float* loss_sum, int B, int h, int w, int C, int ldc,
-                 int s, int ignore_index, s4f_stream stream);
-/* gscale_dev: optional device fp32 scalar multiplied into gscale (the upstream d loss, read without a host sync) */
-int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, float gscale, const float* gscale_dev, float* dlo,
-                 void* dlo_t, int B, int h, int w, int C, int ldc, int s, int ignore_index, int dtype,
+/* lse_out: optional fp32 [B, h*s, w*s]; receives logsumexp(z) of every non-ignored pixel (ignored ones are not written) */
+int s4f_upce_fwd(const float* logits_lo, const uint8_t* labels, float* loss_sum, float* lse_out, int B, int h, int w,
+                 int C, int ldc, int s, int ignore_index, s4f_stream stream);
+/* gscale_dev: optional device fp32 scalar multiplied into gscale (the upstream d loss, read without a host sync).
+ * lse: optional, the lse_out of the matching forward call; with it (s = 2 | 4) the softmax is not re-normalised:
+ * one thread per low-res pixel gathers exp(z - lse) - onehot over the (2s)^2 high-res pixels that read it. */
+int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, const float* lse, float gscale, const float* gscale_dev,
+                 float* dlo, void* dlo_t, int B, int h, int w, int C, int ldc, int s, int ignore_index, int dtype,
                  s4f_stream stream);
 /* Teacher post-processing (encoder_decoder.py:888-901,541-542): label = argmax_c z (first index on ties),
  * conf = 1/sum exp(z - zmax) > th; label_out = conf ? label : 255; conf_count += number of confident pixels.

@@ -64,9 +64,9 @@ _SIGS = {
     's4f_bn_relu_up_bwd': [c_void_p] * 8 + [c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     's4f_bn_bwd_apply': [c_void_p] * 6 + [c_double, c_void_p, c_int64, c_int, c_int, c_void_p],
     's4f_bn_param_grads': [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
-    's4f_upce_fwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    's4f_upce_bwd': [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                     c_int, c_int, c_int, c_void_p],
+    's4f_upce_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_upce_bwd': [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                     c_int, c_int, c_int, c_int, c_void_p],
     's4f_up_pseudo_label': [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int,
                             c_int, c_void_p],
     's4f_up_logits_nchw': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -314,8 +314,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 __global__ __launch_bounds__(256) void upce_fwd_kernel(const float* __restrict__ lo, const uint8_t* __restrict__ labels,
-                                                       float* __restrict__ loss_sum, int B, int h, int w, int C, int ldc,
-                                                       int s, int ignore) {
+                                                       float* __restrict__ loss_sum, float* __restrict__ lse_out, int B,
+                                                       int h, int w, int C, int ldc, int s, int ignore) {
   __shared__ float red[4];
   const int H = h * s, W = w * s;
   const long total = (long)B * H * W;
@@ -338,7 +338,9 @@ __global__ __launch_bounds__(256) void upce_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int c = 0; c < kMaxC; ++c)
       if (c < C) se += expf(z[c] - mx);
-    lsum += (mx + logf(se)) - zl;
+    const float lse = mx + logf(se);
+    if (lse_out) lse_out[i] = lse;
+    lsum += lse - zl;
   }
   const float tot = block_sum_256(lsum, red);
   if (threadIdx.x == 0) atomicAdd(loss_sum, tot);
@@ -487,6 +489,116 @@ __global__ __launch_bounds__(256) void upce_bwd_tiled_kernel(const float* __rest
     const long p = ((long)b * h + ly) * w + lx;
     dlo[p * ldc + c] = acc;
     if (dlo_t) dlo_t[p * ldc + c] = from_f32<T>(acc);
+  }
+}
+
+// Gather variant used when the forward saved logsumexp(z) per high-res pixel (lse): a thread owns one low-res pixel and
+// visits exactly the (2S)^2 high-res pixels that read it.  With lse known every class is independent,
+//   dlo[i,j,c] = sum_px w(px -> i,j) * gscale * (exp(z_c(px) - lse(px)) - [label(px) == c]),
+// z_c(px) is re-interpolated from the 3x3 low-res neighbourhood (separably, the fractional weights are compile-time
+// constants) and the one-hot part is accumulated once per pixel in a private LDS column instead of once per class.
+template <typename T, int S>
+__global__ __launch_bounds__(256) void upce_bwd_lse_kernel(const float* __restrict__ lo, const uint8_t* __restrict__ labels,
+                                                           const float* __restrict__ lse, float gscale,
+                                                           const float* __restrict__ gscale_dev, float* __restrict__ dlo,
+                                                           T* __restrict__ dlo_t, int B, int h, int w, int C, int ldc,
+                                                           int ignore) {
+  constexpr int R = 2 * S;
+  constexpr bool EXACT = sizeof(T) == 4;
+  constexpr float kL2E = 1.4426950408889634f;
+  __shared__ float oh[32 * 256];
+  const int H = h * S, W = w * S;
+  const int tiles_x = (w + 15) >> 4, tiles_y = (h + 15) >> 4;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int tid = threadIdx.x;
+  const int j = tx * 16 + (tid & 15), i = ty * 16 + (tid >> 4);
+  if (i >= h || j >= w) return;                       // no block-level synchronisation below
+  if (gscale_dev) gscale *= *gscale_dev;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) oh[c * 256 + tid] = 0.f;
+  const int oy0 = S * i - S / 2, ox0 = S * j - S / 2;
+  float wy[R], wx[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int oy = oy0 + k, ox = ox0 + k;
+    wy[k] = (oy >= 0 && oy < H) ? lerp_w(oy, i, S, h) : 0.f;
+    wx[k] = (ox >= 0 && ox < W) ? lerp_w(ox, j, S, w) : 0.f;
+  }
+  float wg[R][R], ls[R][R];
+#pragma unroll
+  for (int k = 0; k < R; ++k)
+#pragma unroll
+    for (int l = 0; l < R; ++l) {
+      const float wgt = wy[k] * wx[l];
+      float g = 0.f, lv = 1e30f;
+      if (wgt != 0.f) {
+        const long idx = ((long)b * H + (oy0 + k)) * W + (ox0 + l);
+        const int lab = labels[idx];
+        if (lab != ignore && lab < C) {
+          g = wgt * gscale;
+          lv = EXACT ? lse[idx] : lse[idx] * kL2E;
+          oh[lab * 256 + tid] += g;
+        }
+      }
+      wg[k][l] = g;
+      ls[k][l] = lv;
+    }
+  const int rr[3] = {max(i - 1, 0), i, min(i + 1, h - 1)};
+  const int cc[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
+  const float* P[3][3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) P[m][n] = lo + (((long)b * h + rr[m]) * w + cc[n]) * ldc;
+  const long p = ((long)b * h + i) * w + j;
+#pragma unroll 1
+  for (int c4 = 0; c4 < kMaxC / 4; ++c4) {
+    if (c4 * 4 >= ldc) break;
+    f32x4 out = {0.f, 0.f, 0.f, 0.f};
+    if (c4 * 4 < C) {
+      f32x4 L[3][3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) L[m][n] = *reinterpret_cast<const f32x4*>(P[m][n] + c4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float xr[3][R];
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+          const float a0 = EXACT ? L[m][0][e] : L[m][0][e] * kL2E;
+          const float a1 = EXACT ? L[m][1][e] : L[m][1][e] * kL2E;
+          const float a2 = EXACT ? L[m][2][e] : L[m][2][e] * kL2E;
+#pragma unroll
+          for (int l = 0; l < R; ++l) {
+            const float f = ((l < S ? l : l - S) + 0.5f) / S;
+            xr[m][l] = l < S ? a0 + f * (a1 - a0) : a1 + f * (a2 - a1);
+          }
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const float f = ((k < S ? k : k - S) + 0.5f) / S;
+          const int m0 = k < S ? 0 : 1;
+#pragma unroll
+          for (int l = 0; l < R; ++l) {
+            const float z = xr[m0][l] + f * (xr[m0 + 1][l] - xr[m0][l]);
+            const float pr = EXACT ? expf(z - ls[k][l]) : __builtin_amdgcn_exp2f(z - ls[k][l]);
+            acc += wg[k][l] * pr;
+          }
+        }
+        const int c = c4 * 4 + e;
+        out[e] = c < C ? acc - oh[c * 256 + tid] : 0.f;
+      }
+    }
+    *reinterpret_cast<f32x4*>(dlo + p * ldc + c4 * 4) = out;
+    if (dlo_t) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dlo_t[p * ldc + c4 * 4 + e] = from_f32<T>(out[e]);
+    }
   }
 }
 
@@ -673,22 +785,35 @@ S4F_API int s4f_bn_param_grads(const float* sums_local, float* dgamma, float* db
   S4F_CHECK(B > 0 && h > 0 && w > 0 && s >= 1 && C > 0 && C <= 32 && ldc >= C && ldc % 4 == 0 && ldc <= 32, \
             name ": bad geometry (C=%d ldc=%d s=%d)", C, ldc, s)
 
-S4F_API int s4f_upce_fwd(const float* logits_lo, const uint8_t* labels, float* loss_sum, int B, int h, int w, int C, int ldc,
-                         int s, int ignore_index, s4f_stream stream) {
+S4F_API int s4f_upce_fwd(const float* logits_lo, const uint8_t* labels, float* loss_sum, float* lse_out, int B, int h, int w,
+                         int C, int ldc, int s, int ignore_index, s4f_stream stream) {
   S4F_CHECK(logits_lo && labels && loss_sum, "s4f_upce_fwd: null pointer");
   LOGIT_CHECK("s4f_upce_fwd");
   const long total = (long)B * h * s * w * s;
-  hipLaunchKernelGGL(upce_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, loss_sum, B, h, w, C, ldc, s, ignore_index);
+  hipLaunchKernelGGL(upce_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, loss_sum, lse_out, B, h, w, C, ldc, s, ignore_index);
   S4F_LAUNCH_CHECK();
   return 0;
 }
 
-S4F_API int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, float gscale, const float* gscale_dev, float* dlo,
-                         void* dlo_t, int B, int h, int w, int C, int ldc, int s, int ignore_index, int dtype,
-                         s4f_stream stream) {
+S4F_API int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, const float* lse, float gscale,
+                         const float* gscale_dev, float* dlo, void* dlo_t, int B, int h, int w, int C, int ldc, int s,
+                         int ignore_index, int dtype, s4f_stream stream) {
   DT_CHECK("s4f_upce_bwd");
   S4F_CHECK(logits_lo && labels && dlo, "s4f_upce_bwd: null pointer");
   LOGIT_CHECK("s4f_upce_bwd");
+  if (lse && (s == 2 || s == 4)) {
+    const int nblk = B * ceil_div(h, 16) * ceil_div(w, 16);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S4F_BF16) {
+      if (s == 2) hipLaunchKernelGGL((upce_bwd_lse_kernel<bf16_t, 2>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, ignore_index);
+      else hipLaunchKernelGGL((upce_bwd_lse_kernel<bf16_t, 4>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, ignore_index);
+    } else {
+      if (s == 2) hipLaunchKernelGGL((upce_bwd_lse_kernel<float, 2>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (float*)dlo_t, B, h, w, C, ldc, ignore_index);
+      else hipLaunchKernelGGL((upce_bwd_lse_kernel<float, 4>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (float*)dlo_t, B, h, w, C, ldc, ignore_index);
+    }
+    S4F_LAUNCH_CHECK();
+    return 0;
+  }
   if (s == 2 || s == 4) {
     const int TLv = s == 2 ? 8 : 4;
     const int HR = s * TLv + 2 * s;

@@ -391,11 +391,14 @@ class HeadLossFn(Function):
             raise S4FError(f'labels {tuple(labels_u8.shape)} do not match the logits size {(Bn, H, W)} '
                            '(the identity resize of decode_head.py:322-326 is the only one on the hot path)')
         loss_sum = torch.zeros(1, device=tokens.device)
-        K.upce_fwd(logits, labels_u8, loss_sum, Bn, h, w, hp['num_classes'], LOGIT_LD, s, hp['ignore_index'])
+        # logsumexp per pixel is kept for the backward (4 B / pixel) so that it does not re-normalise the softmax
+        lse = torch.empty(Bn, H, W, device=tokens.device) if need_grad and s in (2, 4) else None
+        K.upce_fwd(logits, labels_u8, loss_sum, Bn, h, w, hp['num_classes'], LOGIT_LD, s, hp['ignore_index'], lse_out=lse)
         k = float(loss_weight) / float(Bn * H * W)
         if need_grad:
             ctx.sv, ctx.hp, ctx.store = sv, hp, store
             ctx.meta = (labels_u8, k, Bn, h, w, s)
+            ctx.lse = lse
         return (loss_sum * k).reshape(())
 
     @staticmethod
@@ -408,7 +411,8 @@ class HeadLossFn(Function):
         dlo_t = torch.empty(logits.shape, device=logits.device, dtype=torch.bfloat16) if code == BF16 else None
         gdev = dloss.detach().reshape(1).to(torch.float32).contiguous()
         K.upce_bwd(logits, labels, k, dlo, dlo_t, Bn, h, w, hp['num_classes'], LOGIT_LD, s, code, hp['ignore_index'],
-                   gscale_dev=gdev)
+                   gscale_dev=gdev, lse=ctx.lse)
+        ctx.lse = None
         dtok = head_backward(dlo, dlo_t if dlo_t is not None else dlo, sv, hp, store)
         ctx.sv = None
         store.node_done()

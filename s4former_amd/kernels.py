@@ -333,20 +333,23 @@ def _chk_u8(t, n, what):
     _need(t, n, what)
 
 
-def upce_fwd(logits_lo, labels, loss_sum, B, h, w, C, ldc, s, ignore_index=255):
+def upce_fwd(logits_lo, labels, loss_sum, B, h, w, C, ldc, s, ignore_index=255, lse_out=None):
     _chk_f32(logits_lo, 'upce logits'); _need(logits_lo, B * h * w * ldc, 'upce logits')
     _chk_u8(labels, B * h * s * w * s, 'upce labels'); _chk_f32(loss_sum, 'upce loss'); _need(loss_sum, 1, 'upce loss')
-    call('s4f_upce_fwd', p(logits_lo), p(labels), p(loss_sum), B, h, w, C, ldc, s, ignore_index, stream())
+    _chk_f32(lse_out, 'upce lse_out'); _need(lse_out, B * h * s * w * s if lse_out is not None else 0, 'upce lse_out')
+    call('s4f_upce_fwd', p(logits_lo), p(labels), p(loss_sum), p(lse_out), B, h, w, C, ldc, s, ignore_index, stream())
 
 
-def upce_bwd(logits_lo, labels, gscale, dlo, dlo_t, B, h, w, C, ldc, s, dtype, ignore_index=255, gscale_dev=None):
+def upce_bwd(logits_lo, labels, gscale, dlo, dlo_t, B, h, w, C, ldc, s, dtype, ignore_index=255, gscale_dev=None,
+             lse=None):
     _chk_f32(logits_lo, 'upce_bwd logits'); _need(logits_lo, B * h * w * ldc, 'upce_bwd logits')
     _chk_u8(labels, B * h * s * w * s, 'upce_bwd labels')
     _chk_f32(dlo, 'upce_bwd dlo'); _need(dlo, B * h * w * ldc, 'upce_bwd dlo')
     _chk_dtype(dlo_t, dtype, 'upce_bwd dlo_t'); _need(dlo_t, B * h * w * ldc if dlo_t is not None else 0, 'upce_bwd dlo_t')
     _chk_f32(gscale_dev, 'upce_bwd gscale_dev'); _need(gscale_dev, 1 if gscale_dev is not None else 0, 'upce_bwd gscale_dev')
-    call('s4f_upce_bwd', p(logits_lo), p(labels), float(gscale), p(gscale_dev), p(dlo), p(dlo_t), B, h, w, C, ldc, s,
-         ignore_index, dtype, stream())
+    _chk_f32(lse, 'upce_bwd lse'); _need(lse, B * h * s * w * s if lse is not None else 0, 'upce_bwd lse')
+    call('s4f_upce_bwd', p(logits_lo), p(labels), p(lse), float(gscale), p(gscale_dev), p(dlo), p(dlo_t), B, h, w, C,
+         ldc, s, ignore_index, dtype, stream())
 
 
 def up_pseudo_label(logits_lo, label_out, conf_out, conf_count, th, B, h, w, C, ldc, s):

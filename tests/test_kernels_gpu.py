@@ -366,6 +366,24 @@ def test_upsample_ce(K, s, C):
     check(dlo[..., :C], to_nhwc(lor.grad), 0, 'upsample+CE dlogits', tol=1e-4)
     assert float(dlo[..., C:].abs().max()) == 0.0, 'padding columns must be zero'
     check(dlo_t[..., :C], to_nhwc(lor.grad), 1, 'upsample+CE dlogits bf16 copy', tol=1e-2)
+    # backward from the logsumexp saved by the forward (the path HeadLossFn takes for s = 2 | 4), fp32 and bf16 flavours
+    if s > 1:
+        lse = torch.full((B, h * s, w * s), float('nan'), device='cuda')
+        ls2 = torch.zeros(1, device='cuda')
+        K.upce_fwd(lod, labd, ls2, B, h, w, C, ldc, s, lse_out=lse)
+        assert abs(float(ls2) - float(ls)) <= 1e-5 * abs(float(ls))      # same kernel, atomic summation order differs
+        ref_lse = torch.logsumexp(z.detach(), dim=1)
+        live = dev(lab != 255)
+        check(lse[live], dev(ref_lse)[live].cpu(), 0, 'saved logsumexp', tol=1e-5)
+        assert bool(torch.isnan(lse[~live]).all()), 'ignored pixels are not written'
+        for code, tol in ((0, 1e-4), (1, 2e-3)):
+            dlo2 = torch.full((B, h, w, ldc), 7.0, device='cuda')
+            dlo2_t = torch.full((B, h, w, ldc), 7.0, device='cuda', dtype=torch.bfloat16 if code else torch.float32)
+            K.upce_bwd(lod, labd, 0.8 / numel, dlo2, dlo2_t, B, h, w, C, ldc, s, code,
+                       gscale_dev=torch.full((1,), 0.5, device='cuda'), lse=lse)
+            check(dlo2[..., :C], to_nhwc(lor.grad), 0, f'upsample+CE dlogits from lse (dtype {code})', tol=tol)
+            assert float(dlo2[..., C:].abs().max()) == 0.0
+            check(dlo2_t[..., :C].float(), to_nhwc(lor.grad), 1, 'upsample+CE dlogits from lse, T copy', tol=1e-2)
     # all-ignored image -> loss 0, grad 0
     lab0 = torch.full((B, h * s, w * s), 255, dtype=torch.uint8)
     ls.zero_()

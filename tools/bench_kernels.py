@@ -131,6 +131,13 @@ lo4 = torch.randn(B, 128, 128, 32, device=dev)
 dlo4 = torch.empty_like(lo4)
 ms = timeit(lambda: K.upce_bwd(lo4, lab, 1.0, dlo4, None, B, 128, 128, 21, 32, 4, code))
 report('upsample+CE bwd s=4', ms, bytes_=lo4.numel() * 8 + lab.numel())
+lse = torch.empty(B, 512, 512, device=dev)
+K.upce_fwd(lo, lab, ls, B, 256, 256, 21, 32, 2, lse_out=lse)
+ms = timeit(lambda: K.upce_bwd(lo, lab, 1.0, dlo, dlot, B, 256, 256, 21, 32, 2, code, lse=lse))
+report('upsample+CE bwd s=2 (saved lse)', ms, bytes_=lo.numel() * 8 + lab.numel() * 5)
+K.upce_fwd(lo4, lab, ls, B, 128, 128, 21, 32, 4, lse_out=lse)
+ms = timeit(lambda: K.upce_bwd(lo4, lab, 1.0, dlo4, None, B, 128, 128, 21, 32, 4, code, lse=lse))
+report('upsample+CE bwd s=4 (saved lse)', ms, bytes_=lo4.numel() * 8 + lab.numel() * 5)
 n = 89_980_949
 t, s = torch.randn(n, device=dev), torch.randn(n, device=dev)
 tt = torch.empty(n, device=dev, dtype=T)
