@@ -117,10 +117,12 @@ int s4f_layernorm_fwd(const float* x, const float* gamma, const float* beta, voi
                       s4f_stream stream);
 /* dx (=|+=) LN backward of dy (T) ; dgamma/dbeta accumulated atomically (fp32).  dx, dx_t and dresid use the
  * same (in_batch_stride) row map as x.  dresid: optional fp32 gradient of the residual branch added to the
- * result.  dx fp32 output, dx_t optional T copy.  accumulate != 0: dx += (instead of =), dresid must be NULL. */
+ * result.  dx fp32 output, dx_t optional T copy.  accumulate != 0: dx += (instead of =), dresid must be NULL.
+ * dcolsum: optional fp32 [C], += column sums of the final dx (the bias gradient of the linear layer whose output this
+ * gradient belongs to: vit.py:113-127, the proj / fc2 biases), accumulated atomically like dgamma / dbeta. */
 int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                      const float* dresid, float* dx, void* dx_t, float* dgamma, float* dbeta, int rows, int C,
-                      int rows_per_img, int64_t in_batch_stride, int accumulate, int dtype, s4f_stream stream);
+                      const float* dresid, float* dx, void* dx_t, float* dgamma, float* dbeta, float* dcolsum, int rows,
+                      int C, int rows_per_img, int64_t in_batch_stride, int accumulate, int dtype, s4f_stream stream);
 
 /* out = a + b (fp32), optional T copy of the sum */
 int s4f_add_f32(const float* a, const float* b, float* out, void* out_t, int64_t n, int dtype, s4f_stream stream);

@@ -52,7 +52,7 @@ _SIGS = {
     's4f_colsum': [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     's4f_layernorm_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64,
                           c_float, c_int, c_void_p],
-    's4f_layernorm_bwd': [c_void_p] * 10 + [c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p],
+    's4f_layernorm_bwd': [c_void_p] * 11 + [c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p],
     's4f_add_f32': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     's4f_attention_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
                           c_void_p],

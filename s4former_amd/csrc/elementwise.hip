@@ -208,76 +208,104 @@ template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
 }
 
 // dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * gamma ; dgamma += dy * xhat ; dbeta += dy
+// out = dx (+ dresid | + previous out);  dcolsum (optional) += column sums of out (= the bias gradient of the linear
+// layer that produced the residual branch this gradient flows into).
+// A wave owns two adjacent rows per iteration and issues every load of both (x, dy, dresid) before the first reduction.
 template <typename T, int NV>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ dresid,
                                                      float* __restrict__ dx, T* __restrict__ dx_t,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows,
-                                                     int rows_per_img, long bstride, int accumulate) {
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ dcolsum, int rows, int rows_per_img, long bstride,
+                                                     int accumulate) {
   constexpr int C = NV * 256;
-  __shared__ float red[2][4][C];
+  constexpr int U = 2;
+  __shared__ float red[3][4][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
-  f32x4 gm[NV], dg[NV], db[NV];
+  f32x4 gm[NV], dg[NV], db[NV], dc[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) {
     gm[v] = *reinterpret_cast<const f32x4*>(gamma + v * 256 + lane * 4);
     dg[v] = f32x4{0.f, 0.f, 0.f, 0.f};
     db[v] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dc[v] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  for (int r = wave_global; r < rows; r += nwaves) {
-    const long io = ln_in_off(r, rows_per_img, bstride, C);
-    const float* xr = x + io;
-    const T* dyr = dy + (long)r * C;
-    const float mu = mean[r], rs = rstd[r];
-    f32x4 xh[NV], dyv[NV];
-    float s1 = 0.f, s2 = 0.f;
+  const bool has_prev = dresid != nullptr || accumulate;
+  for (int r0 = wave_global * U; r0 < rows; r0 += nwaves * U) {
+    long io[U];
+    bool live[U];
+    f32x4 xh[U][NV], dyv[U][NV], pv[U][NV];
+    float mu[U], rs[U];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + v * 256 + lane * 4);
-      dyv[v] = load4<T>(dyr + v * 256 + lane * 4);
+    for (int u = 0; u < U; ++u) {
+      live[u] = r0 + u < rows;
+      const int r = live[u] ? r0 + u : r0;
+      io[u] = ln_in_off(r, rows_per_img, bstride, C);
+      mu[u] = mean[r]; rs[u] = rstd[r];
+      const float* prev = dresid ? dresid + io[u] : dx + io[u];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        xh[v][e] = (xv[e] - mu) * rs;
-        const float dyg = dyv[v][e] * gm[v][e];
-        s1 += dyg;
-        s2 += dyg * xh[v][e];
-        dg[v][e] += dyv[v][e] * xh[v][e];
-        db[v][e] += dyv[v][e];
+      for (int v = 0; v < NV; ++v) {
+        xh[u][v] = *reinterpret_cast<const f32x4*>(x + io[u] + v * 256 + lane * 4);
+        dyv[u][v] = load4<T>(dy + (long)r * C + v * 256 + lane * 4);
+        if (has_prev) pv[u][v] = *reinterpret_cast<const f32x4*>(prev + v * 256 + lane * 4);
+        else pv[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    s1 = wave_sum(s1) * (1.f / C);
-    s2 = wave_sum(s2) * (1.f / C);
+    float s1[U], s2[U];
 #pragma unroll
-    for (int v = 0; v < NV; ++v) {
-      f32x4 o;
+    for (int u = 0; u < U; ++u) {
+      s1[u] = 0.f; s2[u] = 0.f;
+      const float lv = live[u] ? 1.f : 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = rs * (dyv[v][e] * gm[v][e] - s1 - xh[v][e] * s2);
-      float* dxr = dx + io + v * 256 + lane * 4;
-      if (dresid) {
-        const f32x4 dr = *reinterpret_cast<const f32x4*>(dresid + io + v * 256 + lane * 4);
-        o += dr;
-      } else if (accumulate) {
-        o += *reinterpret_cast<const f32x4*>(dxr);
+      for (int v = 0; v < NV; ++v)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[u][v][e] = (xh[u][v][e] - mu[u]) * rs[u];
+          dyv[u][v][e] *= lv;
+          const float dyg = dyv[u][v][e] * gm[v][e];
+          s1[u] += dyg;
+          s2[u] += dyg * xh[u][v][e];
+          dg[v][e] += dyv[u][v][e] * xh[u][v][e];
+          db[v][e] += dyv[u][v][e];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s1[u] = wave_sum(s1[u]) * (1.f / C);
+      s2[u] = wave_sum(s2[u]) * (1.f / C);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!live[u]) continue;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs[u] * (dyv[u][v][e] * gm[v][e] - s1[u] - xh[u][v][e] * s2[u]);
+        o += pv[u][v];
+        dc[v] += o;
+        *reinterpret_cast<f32x4*>(dx + io[u] + v * 256 + lane * 4) = o;
+        if (dx_t) store4<T>(dx_t + io[u] + v * 256 + lane * 4, o);
       }
-      *reinterpret_cast<f32x4*>(dxr) = o;
-      if (dx_t) store4<T>(dx_t + io + v * 256 + lane * 4, o);
     }
   }
-  // block reduction of dgamma / dbeta, then one atomic per column per block
+  // block reduction of dgamma / dbeta / dcolsum, then one atomic per column per block
 #pragma unroll
   for (int v = 0; v < NV; ++v)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       red[0][wave][v * 256 + lane * 4 + e] = dg[v][e];
       red[1][wave][v * 256 + lane * 4 + e] = db[v][e];
+      red[2][wave][v * 256 + lane * 4 + e] = dc[v][e];
     }
   __syncthreads();
   for (int c = threadIdx.x; c < C; c += 256) {
     atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
     atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    if (dcolsum) atomicAdd(dcolsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
   }
 }
 
@@ -437,8 +465,9 @@ S4F_API int s4f_layernorm_fwd(const float* x, const float* gamma, const float* b
 }
 
 S4F_API int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                              const float* dresid, float* dx, void* dx_t, float* dgamma, float* dbeta, int rows, int C,
-                              int rows_per_img, int64_t in_batch_stride, int accumulate, int dtype, s4f_stream stream) {
+                              const float* dresid, float* dx, void* dx_t, float* dgamma, float* dbeta, float* dcolsum,
+                              int rows, int C, int rows_per_img, int64_t in_batch_stride, int accumulate, int dtype,
+                              s4f_stream stream) {
   DT_CHECK("s4f_layernorm_bwd");
   S4F_CHECK(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "s4f_layernorm_bwd: null pointer");
   S4F_CHECK(rows > 0 && C % 256 == 0 && C >= 256 && C <= 1024, "s4f_layernorm_bwd: C=%d must be a multiple of 256, <= 1024", C);
@@ -447,8 +476,8 @@ S4F_API int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean,
   const long bstride = (long)in_batch_stride;
   int grid = grid_for(rows, 16);   // 4 rows per wave: fewer atomics on dgamma/dbeta
   if (grid > 512) grid = 512;
-  if (dtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)dy, x, mean, rstd, gamma, dresid, dx, (bf16_t*)dx_t, dgamma, dbeta, rows, rows_per_img, bstride, accumulate) }
-  else { LN_DISPATCH(ln_bwd_kernel, float, (const float*)dy, x, mean, rstd, gamma, dresid, dx, (float*)dx_t, dgamma, dbeta, rows, rows_per_img, bstride, accumulate) }
+  if (dtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)dy, x, mean, rstd, gamma, dresid, dx, (bf16_t*)dx_t, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
+  else { LN_DISPATCH(ln_bwd_kernel, float, (const float*)dy, x, mean, rstd, gamma, dresid, dx, (float*)dx_t, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
   S4F_LAUNCH_CHECK();
   return 0;
 }

@@ -239,6 +239,152 @@ __global__ __launch_bounds__(256) void bn_relu_up_bwd_kernel(const T* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------ S = 2 | 4 specialisations
+// align_corners=False by an integer factor S: output o = S*i + r reads inputs (i-1, i) with fraction (r + S/2 + .5)/S
+// when r < S/2 and (i, i+1) with fraction (r - S/2 + .5)/S otherwise; at the borders the neighbour index is clamped, which
+// reproduces torch's clamped source coordinate (a convex combination of a value with itself).  Conversely input i is read
+// by the 2S outputs o = S*i - S/2 + k, k < 2S, with weight (k+.5)/S (k < S) or 1 - (k-S+.5)/S (k >= S); the outputs that
+// would have shared their weight with the missing neighbour at a border give all of it (weight 1).
+template <int S> __device__ __forceinline__ constexpr float up_frac(int r) {
+  return ((r < S / 2 ? r + S / 2 : r - S / 2) + 0.5f) / S;
+}
+template <int S> __device__ __forceinline__ float down_weight(int k, int i, int n_in) {   // k in [0, 2S)
+  const int o = S * i - S / 2 + k;
+  if (o < 0 || o >= S * n_in) return 0.f;
+  if (k < S) return (i == 0) ? 1.f : (k + 0.5f) / S;
+  return (i == n_in - 1) ? 1.f : 1.f - (k - S + 0.5f) / S;
+}
+
+// One block per low-res row (grid-strided), thread = (low-res pixel, 16-byte channel chunk): loads the 3x3 neighbourhood
+// once, applies BN + ReLU, and writes the S x S outputs of its cell.  No integer division in the pixel loop.
+template <typename T, int S>
+__global__ __launch_bounds__(256) void bn_relu_up_fwd_s_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, T* __restrict__ y, int B,
+                                                               int h, int w, int C) {
+  constexpr int N = VT<T>::N;
+  const int CPR = C / N, PPB = 256 / CPR;
+  const int cc = threadIdx.x % CPR, pl = threadIdx.x / CPR;
+  const int H = h * S, W = w * S;
+  float sc[N], sh[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) { sc[e] = scale[cc * N + e]; sh[e] = shift[cc * N + e]; }
+  const int rows = B * h;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int b = row / h, i = row - b * h;
+    const int rr[3] = {max(i - 1, 0), i, min(i + 1, h - 1)};
+    for (int j = pl; j < w; j += PPB) {
+      const int cj[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
+      float a[3][3][N];
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          VT<T>::load(x + (((long)b * h + rr[m]) * w + cj[n]) * C + cc * N, a[m][n]);
+#pragma unroll
+          for (int e = 0; e < N; ++e) a[m][n][e] = fmaxf(a[m][n][e] * sc[e] + sh[e], 0.f);
+        }
+#pragma unroll
+      for (int l = 0; l < S; ++l) {
+        const int n0 = l < S / 2 ? 0 : 1;
+        const float fx = up_frac<S>(l);
+        float xi[3][N];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int e = 0; e < N; ++e) xi[m][e] = a[m][n0][e] + fx * (a[m][n0 + 1][e] - a[m][n0][e]);
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+          const int m0 = r < S / 2 ? 0 : 1;
+          const float fy = up_frac<S>(r);
+          float o[N];
+#pragma unroll
+          for (int e = 0; e < N; ++e) o[e] = xi[m0][e] + fy * (xi[m0 + 1][e] - xi[m0][e]);
+          VT<T>::store(y + (((long)b * H + S * i + r) * W + S * j + l) * C + cc * N, o);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int S>
+__global__ __launch_bounds__(256) void bn_relu_up_bwd_s_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               T* __restrict__ g, float* __restrict__ sums, int B, int h,
+                                                               int w, int C) {
+  constexpr int N = VT<T>::N;
+  constexpr int R = 2 * S;
+  extern __shared__ float red[];          // [PPB][2][C]
+  const int CPR = C / N, PPB = 256 / CPR;
+  const int cc = threadIdx.x % CPR, pl = threadIdx.x / CPR;
+  const int H = h * S, W = w * S;
+  float sc[N], sh[N], mu[N], rs[N], sg[N], sgx[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    sc[e] = scale[cc * N + e]; sh[e] = shift[cc * N + e]; mu[e] = mean[cc * N + e]; rs[e] = rstd[cc * N + e];
+    sg[e] = 0.f; sgx[e] = 0.f;
+  }
+  const int rows = B * h;
+  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+    const int b = row / h, i = row - b * h;
+    float wy[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) wy[k] = down_weight<S>(k, i, h);
+    const int oy0 = S * i - S / 2;
+    for (int j = pl; j < w; j += PPB) {
+      float wx[R];
+#pragma unroll
+      for (int l = 0; l < R; ++l) wx[l] = down_weight<S>(l, j, w);
+      const int ox0 = S * j - S / 2;
+      float acc[N];
+#pragma unroll
+      for (int e = 0; e < N; ++e) acc[e] = 0.f;
+      // out-of-image taps carry weight 0 and a clamped (valid) address: the 4 S^2 loads stay branch-free and independent
+#pragma unroll
+      for (int k = 0; k < R; ++k) {
+        const int oy = min(max(oy0 + k, 0), H - 1);
+        const T* rowp = dy + (((long)b * H + oy) * W) * C + cc * N;
+        float t[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) t[e] = 0.f;
+#pragma unroll
+        for (int l = 0; l < R; ++l) {
+          const int ox = min(max(ox0 + l, 0), W - 1);
+          float f[N];
+          VT<T>::load(rowp + (long)ox * C, f);
+#pragma unroll
+          for (int e = 0; e < N; ++e) t[e] += wx[l] * f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] += wy[k] * t[e];
+      }
+      const long p = (long)row * w + j;
+      float xv[N];
+      VT<T>::load(x + p * C + cc * N, xv);
+#pragma unroll
+      for (int e = 0; e < N; ++e) {
+        const float gg = (xv[e] * sc[e] + sh[e] > 0.f) ? acc[e] : 0.f;
+        acc[e] = gg;
+        sg[e] += gg;
+        sgx[e] += gg * (xv[e] - mu[e]) * rs[e];
+      }
+      VT<T>::store(g + p * C + cc * N, acc);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    red[(pl * 2 + 0) * C + cc * N + e] = sg[e];
+    red[(pl * 2 + 1) * C + cc * N + e] = sgx[e];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * C; k += 256) {
+    const int which = k / C, c = k % C;
+    float t = 0.f;
+    for (int r = 0; r < PPB; ++r) t += red[(r * 2 + which) * C + c];
+    atomicAdd(sums + which * C + c, t);
+  }
+}
+
 // pass 2: dx = gamma * rstd * (g - sum_g/n - xhat * sum_gx/n)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x,
@@ -735,6 +881,20 @@ S4F_API int s4f_bn_relu_up_fwd(const void* x, const float* scale, const float* s
   DT_CHECK("s4f_bn_relu_up_fwd");
   S4F_CHECK(x && scale && shift && y && B > 0 && h > 0 && w > 0 && s >= 1, "s4f_bn_relu_up_fwd: bad args");
   CH_CHECK("s4f_bn_relu_up_fwd");
+  if (s == 2 || s == 4) {
+    const int rows = B * h;
+    const int grid = rows < 4096 ? rows : 4096;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S4F_BF16) {
+      if (s == 2) hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, B, h, w, C);
+      else hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, B, h, w, C);
+    } else {
+      if (s == 2) hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<float, 2>), dim3(grid), dim3(256), 0, st, (const float*)x, scale, shift, (float*)y, B, h, w, C);
+      else hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<float, 4>), dim3(grid), dim3(256), 0, st, (const float*)x, scale, shift, (float*)y, B, h, w, C);
+    }
+    S4F_LAUNCH_CHECK();
+    return 0;
+  }
   const long total = (long)B * h * s * w * s * (C / (dtype == S4F_BF16 ? 8 : 4));
   const int grid = grid_for(total, 256);
   if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_relu_up_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, scale, shift, (bf16_t*)y, B, h, w, C, s);
@@ -754,6 +914,20 @@ S4F_API int s4f_bn_relu_up_bwd(const void* dy, const void* x, const float* scale
   const long npix = (long)B * h * w;
   int grid = grid_for(npix, rl * 4);
   const size_t shm = (size_t)rl * 2 * C * sizeof(float);
+  if (s == 2 || s == 4) {
+    const int rows = B * h;
+    const int g2 = rows < 512 ? rows : 512;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == S4F_BF16) {
+      if (s == 2) hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<bf16_t, 2>), dim3(g2), dim3(256), shm, st, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, rstd, (bf16_t*)g, sums, B, h, w, C);
+      else hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<bf16_t, 4>), dim3(g2), dim3(256), shm, st, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, rstd, (bf16_t*)g, sums, B, h, w, C);
+    } else {
+      if (s == 2) hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<float, 2>), dim3(g2), dim3(256), shm, st, (const float*)dy, (const float*)x, scale, shift, mean, rstd, (float*)g, sums, B, h, w, C);
+      else hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<float, 4>), dim3(g2), dim3(256), shm, st, (const float*)dy, (const float*)x, scale, shift, mean, rstd, (float*)g, sums, B, h, w, C);
+    }
+    S4F_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_relu_up_bwd_kernel<bf16_t>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, rstd, (bf16_t*)g, sums, B, h, w, C, s);
   else hipLaunchKernelGGL(bn_relu_up_bwd_kernel<float>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const float*)dy, (const float*)x, scale, shift, mean, rstd, (float*)g, sums, B, h, w, C, s);
   S4F_LAUNCH_CHECK();

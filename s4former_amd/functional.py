@@ -104,6 +104,14 @@ def _as_T(x_f32, code):
     return out
 
 
+def _handed_colsum(g):
+    """column sums [E] of a gradient tensor if the node that produced it left them on it (LayerFn.backward), else None"""
+    cached = getattr(g, '_s4f_colsum', None)
+    if cached is not None and cached[1] == g._version and cached[2] == g.data_ptr():
+        return cached[0]
+    return None
+
+
 def _wgrad(dy, x, M, N, rows, ldm, ldn, out, code):
     """out[M,N] += dy[rows,M]^T x[rows,N]   (fp32 atomic accumulate into the gradient arena)"""
     K.gemm(dy, x, M, N, rows, ldm, ldn, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=out, ldo_f32=N, atomic=True,
@@ -200,10 +208,14 @@ class LayerFn(Function):
         dev = g2.device
         g2 = g2.contiguous()
         g2t = _as_T(g2, code)
+        g2cs = _handed_colsum(g2)
         # ---- FFN
         with on_side(dev, g2t, sv['a']):
             _wgrad(g2t, sv['a'], E, F_, M, E, F_, store.grad_phys(w2), code)
-            K.colsum(g2t, E, M, E, store.grad_phys(bf2), code)
+            if g2cs is None:
+                K.colsum(g2t, E, M, E, store.grad_phys(bf2), code)
+        if g2cs is not None:
+            store.grad_phys(bf2).add_(g2cs)
         dz = torch.empty(M, F_, device=dev, dtype=T)
         K.gemm(g2t, store.shadow(w2), M, F_, E, E, F_, code, b_mode=K.OP_K, out_t=dz, ldo_t=F_, aux=sv['z'], ld_aux=F_,
                act=K.ACT_GELU_BWD)
@@ -216,14 +228,14 @@ class LayerFn(Function):
         del dz
         g1 = torch.empty(Bn, N, E, device=dev)
         g1t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
+        # the column sums of g1 (= the proj bias gradient) come out of the same pass
         K.layernorm_bwd(dxn2, sv['x1'], sv['mean2'], sv['rstd2'], store.phys(gm2), g2, g1, g1t, store.grad_phys(gm2),
-                        store.grad_phys(b2), M, E, code)
+                        store.grad_phys(b2), M, E, code, dcolsum=store.grad_phys(bo))
         if g1t is None:
             g1t = g1
         # ---- attention
         with on_side(dev, g1t, sv['ctxv']):
             _wgrad(g1t, sv['ctxv'], E, E, M, E, E, store.grad_phys(wo), code)
-            K.colsum(g1t, E, M, E, store.grad_phys(bo), code)
         dctx = torch.empty(M, E, device=dev, dtype=T)
         K.gemm(g1t, store.shadow(wo), M, E, E, E, E, code, b_mode=K.OP_K, out_t=dctx, ldo_t=E)
         dqkv = torch.empty(M, 3 * E, device=dev, dtype=T)
@@ -238,12 +250,14 @@ class LayerFn(Function):
         del dqkv
         g0 = torch.empty(Bn, N, E, device=dev)
         g0t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
+        g0cs = torch.zeros(E, device=dev)
         K.layernorm_bwd(dxn, sv['x'], sv['mean1'], sv['rstd1'], store.phys(gm1), g1, g0, g0t, store.grad_phys(gm1),
-                        store.grad_phys(b1), M, E, code)
+                        store.grad_phys(b1), M, E, code, dcolsum=g0cs)
+        # reused by the previous layer if autograd hands this very tensor through unmodified (autograd may
+        # accumulate other branches into it in place: the version counter catches that)
         if g0t is not None:
-            # reused by the previous layer if autograd hands this very tensor through unmodified (autograd may
-            # accumulate other branches into it in place: the version counter catches that)
             g0._s4f_t = (g0t, g0._version, g0.data_ptr())
+        g0._s4f_colsum = (g0cs, g0._version, g0.data_ptr())
         ctx.sv = None
         store.node_done()
         store.range_done(*ctx.range)

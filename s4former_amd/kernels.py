@@ -226,7 +226,7 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, dtype, eps, rows_per_i
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dresid, dx, dx_t, dgamma, dbeta, rows, C, dtype, rows_per_img=0,
-                  in_batch_stride=0, accumulate=False):
+                  in_batch_stride=0, accumulate=False, dcolsum=None):
     if rows_per_img <= 0:
         rows_per_img, in_batch_stride = rows, 0
     if rows % rows_per_img:
@@ -239,8 +239,9 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dresid, dx, dx_t, dgamma, dbeta, row
     _need_span(dresid, nin, 'ln_bwd dresid'); _need_span(dx_t, nin, 'ln_bwd dx_t')
     _need(mean, rows, 'ln_bwd mean'); _need(rstd, rows, 'ln_bwd rstd')
     _need(gamma, C, 'ln_bwd gamma'); _need(dgamma, C, 'ln_bwd dgamma'); _need(dbeta, C, 'ln_bwd dbeta')
+    _chk_f32(dcolsum, 'ln_bwd dcolsum'); _need(dcolsum, C if dcolsum is not None else 0, 'ln_bwd dcolsum')
     call('s4f_layernorm_bwd', p(dy), p(x), p(mean), p(rstd), p(gamma), p(dresid), p(dx), p(dx_t), p(dgamma), p(dbeta),
-         rows, C, rows_per_img, in_batch_stride, 1 if accumulate else 0, dtype, stream())
+         p(dcolsum), rows, C, rows_per_img, in_batch_stride, 1 if accumulate else 0, dtype, stream())
 
 
 def add_f32(a, b, out, out_t, dtype):

@@ -203,9 +203,11 @@ def test_layernorm(K, code, skip):
     dx = torch.zeros(B, ntok, C, device='cuda')
     dx_t = torch.zeros(B, ntok, C, device='cuda', dtype=tdt(code))
     dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dcs = torch.full((C,), 2.0, device='cuda')
     K.layernorm_bwd(dev(dy, code), xv, mean, rstd, dev(gamma), dev(dres)[:, skip:], dx[:, skip:], dx_t[:, skip:], dg, db,
-                    rows, C, code, rows_per_img=ntok - skip, in_batch_stride=ntok * C)
+                    rows, C, code, rows_per_img=ntok - skip, in_batch_stride=ntok * C, dcolsum=dcs)
     ref_dx = (xin.grad.reshape(B, ntok - skip, C) + dres[:, skip:])
+    check(dcs, 2.0 + ref_dx.reshape(-1, C).sum(0), code, 'layernorm column sums of dx', tol=2e-4 if code == 0 else 1e-2)
     check(dx[:, skip:], ref_dx, code, 'layernorm dx (+resid)', tol=1e-4 if code == 0 else 1e-2)
     check(dx_t[:, skip:], ref_dx, code, 'layernorm dx T copy', tol=1e-4 if code == 0 else 1e-2)
     check(dg, g.grad, code, 'layernorm dgamma', tol=2e-4 if code == 0 else 1e-2)
