@@ -205,11 +205,12 @@ def main():
         summ = prof.summary()
         fam = {}
         for (name, tag), d in summ.items():
-            key = name if name != 's4f_gemm' else f's4f_gemm[a{tag[0]},b{tag[1]}]'
+            is_gemm = name in ('s4f_gemm', 's4f_gemm_grouped') and tag is not None
+            key = name if not is_gemm else f's4f_gemm[a{tag[0]},b{tag[1]}]'
             f = fam.setdefault(key, dict(calls=0, ms=0.0, gflop=0.0))
             f['calls'] += d['calls']
             f['ms'] += d['ms']
-            if name == 's4f_gemm':
+            if is_gemm:
                 f['gflop'] += d['calls'] * 2.0 * tag[2] * tag[3] * tag[4] / 1e9
         shapes = {}
         for (name, tag), d in summ.items():

@@ -86,6 +86,11 @@ typedef struct s4f_gemm_desc {
 
 int s4f_gemm(const s4f_gemm_desc* d, s4f_stream stream);
 
+/* count (1..4) independent problems, same result as count s4f_gemm calls.  Weight-gradient problems (both operands
+ * k-major, atomic fp32 output, bf16, tile_hint 2..4 equal in all) run as ONE grid: the four dW GEMMs of an encoder layer
+ * (F.linear backward x4, vit.py:99-127) have 9..36 output tiles each, together they need a much shallower split-K. */
+int s4f_gemm_grouped(const s4f_gemm_desc* descs, int count, s4f_stream stream);
+
 /* ------------------------------------------------------------------------------------------- elementwise
  * s4f_cast: fp32 -> T copy of n elements (parameter shadows).  */
 int s4f_cast(const float* src, void* dst, int64_t n, int dtype, s4f_stream stream);

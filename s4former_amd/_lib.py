@@ -44,6 +44,7 @@ class GemmDesc(Structure):
 
 _SIGS = {
     's4f_gemm': [POINTER(GemmDesc), c_void_p],
+    's4f_gemm_grouped': [POINTER(GemmDesc), c_int, c_void_p],
     's4f_cast': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     's4f_cast_back': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     's4f_im2col_patch16': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],

@@ -384,3 +384,37 @@ S4F_API int s4f_gemm(const s4f_gemm_desc* dp, s4f_stream stream) {
   S4F_LAUNCH_CHECK();
   return rc;
 }
+
+int s4f_gemm2_grouped_try(const s4f_gemm_desc* ds, int count, hipStream_t st);
+
+S4F_API int s4f_gemm_grouped(const s4f_gemm_desc* descs, int count, s4f_stream stream) {
+  S4F_CHECK(descs != nullptr && count >= 1 && count <= 4, "s4f_gemm_grouped: 1..4 descriptors");
+  bool same = true;
+  for (int i = 0; i < count; ++i) {
+    const s4f_gemm_desc& d = descs[i];
+    S4F_CHECK(d.A && d.B && d.M > 0 && d.N > 0 && d.K > 0, "s4f_gemm_grouped: bad problem %d", i);
+    same = same && d.a_mode == descs[0].a_mode && d.b_mode == descs[0].b_mode && d.dtype == descs[0].dtype &&
+           d.tile_hint == descs[0].tile_hint;
+  }
+  const s4f_gemm_desc& d0 = descs[0];
+  bool groupable = same && count > 1 && d0.dtype == S4F_BF16 && d0.a_mode == S4F_OP_K && d0.b_mode == S4F_OP_K &&
+                   d0.tile_hint >= 2 && d0.tile_hint <= 4;
+  for (int i = 0; i < count && groupable; ++i) {
+    const s4f_gemm_desc& d = descs[i];
+    groupable = d.atomic && d.out_f32 && !d.out_t && !d.out_pre && d.act == S4F_ACT_NONE && !d.bias && !d.resid && !d.pos &&
+                d.lda % 8 == 0 && d.ldb % 8 == 0 && ((uintptr_t)d.A % 16) == 0 && ((uintptr_t)d.B % 16) == 0 &&
+                (d.tile_hint == 2 || d.N % 256 == 0);
+  }
+  if (groupable) {
+    const int rc = s4f_gemm2_grouped_try(descs, count, (hipStream_t)stream);
+    if (rc != -100) {
+      S4F_LAUNCH_CHECK();
+      return rc;
+    }
+  }
+  for (int i = 0; i < count; ++i) {
+    const int rc = s4f_gemm(&descs[i], stream);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}

@@ -225,7 +225,7 @@ __device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, i
 }
 
 template <int BN, int AMODE, int BMODE, int NW>
-__global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
+__device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, const int bz) {
   constexpr bool AK = (AMODE == S4F_OP_K);
   constexpr bool BKM = (BMODE == S4F_OP_K || BMODE == S4F_OP_K_TAPSPLIT || BMODE == S4F_OP_K_CONV);
   constexpr bool TRMAP = AK || BKM;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
   const s4f_gemm_desc& d = args.d;
   // XCD-aware bijective remap of the linear block id (blocks b and b+8 share an XCD / L2)
   const int nt = args.tiles_m * args.tiles_n;
-  int L = blockIdx.x;
+  int L = bx;
   {
     const int xcd = L & 7, q8 = nt >> 3, r8 = nt & 7;
     const int basei = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
     tn = r / rows_here;
   }
   const int m0 = tm * BM, n0 = tn * BN;
-  const int kt_beg = blockIdx.z * args.nk_per_split;
+  const int kt_beg = bz * args.nk_per_split;
   int kt_end = kt_beg + args.nk_per_split;
   if (kt_end > args.nk) kt_end = args.nk;
 
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
   __syncthreads();
 
   // ------------------------------------------------------------------ epilogue (same contract as gemm.hip)
-  const bool first_split = (blockIdx.z == 0);
+  const bool first_split = (bz == 0);
   // Fast path: the tile goes through LDS (fp32, two passes of 128 rows) and leaves with 16-byte-per-lane row-
   // contiguous accesses (outputs, residual, aux, pos all coalesced).  A 2-byte-per-lane store of the raw C layout
   // costs one memory instruction per 64 elements: ~1000 store instructions per tile, the dominant cost at K = 768.
@@ -478,6 +478,34 @@ __global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
   });
 }
 
+template <int BN, int AMODE, int BMODE, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
+  gemm2_body<BN, AMODE, BMODE, NW>(args, blockIdx.x, blockIdx.z);
+}
+
+// Up to four independent problems of the same operand modes in one grid (the four weight-gradient GEMMs of an encoder
+// layer: each alone has too few output tiles for 256 CUs and would need a deep split-K with its atomic traffic).
+constexpr int kMaxGroup = 4;
+struct GroupArgs {
+  GemmArgs p[kMaxGroup];
+  int tile_end[kMaxGroup];
+};
+
+template <int BN, int AMODE, int BMODE, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm2_grouped_kernel(const GroupArgs g) {
+  const int bx = blockIdx.x;
+  int which = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i) which += bx >= g.tile_end[i] ? 1 : 0;
+  GemmArgs args = g.p[0];
+  int start = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (which == i) { args = g.p[i]; start = g.tile_end[i - 1]; }
+  if ((int)blockIdx.z * args.nk_per_split >= args.nk) return;      // this problem has fewer k-splits than the grid
+  gemm2_body<BN, AMODE, BMODE, NW>(args, bx - start, blockIdx.z);
+}
+
 template <int BN, int AM, int BMo, int NW>
 int launch(const s4f_gemm_desc& d, hipStream_t st) {
   GemmArgs a;
@@ -505,6 +533,42 @@ int launch(const s4f_gemm_desc& d, hipStream_t st) {
   return 0;
 }
 
+template <int BN, int AM, int BMo, int NW>
+int launch_grouped(const s4f_gemm_desc* ds, int count, hipStream_t st) {
+  GroupArgs g;
+  int total = 0, zmax = 1;
+  for (int i = 0; i < kMaxGroup; ++i) {
+    const s4f_gemm_desc& d = ds[i < count ? i : count - 1];
+    GemmArgs& a = g.p[i];
+    a.d = d;
+    a.nk = ceil_div(d.K, BK);
+    int sk = d.splitk < 1 ? 1 : d.splitk;
+    if (sk > a.nk) sk = a.nk;
+    a.nk_per_split = ceil_div(a.nk, sk);
+    sk = ceil_div(a.nk, a.nk_per_split);
+    a.tiles_m = ceil_div(d.M, BM);
+    a.tiles_n = ceil_div(d.N, BN);
+    if (i < count) {
+      total += a.tiles_m * a.tiles_n;
+      if (sk > zmax) zmax = sk;
+    }
+    g.tile_end[i] = total;
+  }
+  using FA = Feeder<AM, true, BM, NW>;
+  using FB = Feeder<BMo, false, BN, NW>;
+  size_t shm = 2 * (size_t)(FA::BYTES + FB::BYTES);
+  const size_t epi = (size_t)128 * (BN + 4) * 4;
+  if (shm < epi) shm = epi;
+  static bool attr_set = false;
+  auto kern = gemm2_grouped_kernel<BN, AM, BMo, NW>;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(total, 1, zmax), dim3(64 * NW), shm, st, g);
+  return 0;
+}
+
 template <int BN, int NW>
 int dispatch(const s4f_gemm_desc& d, hipStream_t st) {
   const int am = d.a_mode, bm = d.b_mode;
@@ -525,4 +589,16 @@ int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn) {
   if (d.b_mode == S4F_OP_K_CONV && (d.cC % 256) != 0 && bn == 256) return -100;   // tap must be uniform per N tile
   if (bn == 256) return d.tile_hint == 4 ? g2::dispatch<256, 16>(d, st) : g2::dispatch<256, 8>(d, st);
   return g2::dispatch<128, 8>(d, st);
+}
+
+// grouped entry (s4f_gemm_grouped, gemm.hip): weight-gradient form only (both operands k-major, atomic fp32 output)
+int s4f_gemm2_grouped_try(const s4f_gemm_desc* ds, int count, hipStream_t st) {
+  const s4f_gemm_desc& d = ds[0];
+  if (d.dtype != S4F_BF16 || d.a_mode != S4F_OP_K || d.b_mode != S4F_OP_K) return -100;
+  switch (d.tile_hint) {
+    case 2: return g2::launch_grouped<128, S4F_OP_K, S4F_OP_K, 8>(ds, count, st);
+    case 3: return g2::launch_grouped<256, S4F_OP_K, S4F_OP_K, 8>(ds, count, st);
+    case 4: return g2::launch_grouped<256, S4F_OP_K, S4F_OP_K, 16>(ds, count, st);
+    default: return -100;
+  }
 }

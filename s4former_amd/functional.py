@@ -210,22 +210,22 @@ class LayerFn(Function):
         g2t = _as_T(g2, code)
         g2cs = _handed_colsum(g2)
         # ---- FFN
-        with on_side(dev, g2t, sv['a']):
-            _wgrad(g2t, sv['a'], E, F_, M, E, F_, store.grad_phys(w2), code)
-            if g2cs is None:
+        # The four weight gradients of the layer go out as ONE grouped launch on the side stream once the last operand
+        # (dqkv) exists: alone each has 9..36 output tiles and needs a deep split-K; together they fill the chip.
+        a_act, xn2, ctxv, xn = sv['a'], sv['xn2'], sv['ctxv'], sv['xn']
+        if g2cs is None:
+            with on_side(dev, g2t):
                 K.colsum(g2t, E, M, E, store.grad_phys(bf2), code)
-        if g2cs is not None:
+        else:
             store.grad_phys(bf2).add_(g2cs)
         dz = torch.empty(M, F_, device=dev, dtype=T)
         K.gemm(g2t, store.shadow(w2), M, F_, E, E, F_, code, b_mode=K.OP_K, out_t=dz, ldo_t=F_, aux=sv['z'], ld_aux=F_,
                act=K.ACT_GELU_BWD)
         sv['z'] = sv['a'] = None
-        with on_side(dev, dz, sv['xn2']):
-            _wgrad(dz, sv['xn2'], F_, E, M, F_, E, store.grad_phys(w1), code)
+        with on_side(dev, dz):
             K.colsum(dz, F_, M, F_, store.grad_phys(bf1), code)
         dxn2 = torch.empty(M, E, device=dev, dtype=T)
         K.gemm(dz, store.shadow(w1), M, E, F_, F_, E, code, b_mode=K.OP_K, out_t=dxn2, ldo_t=E)
-        del dz
         g1 = torch.empty(Bn, N, E, device=dev)
         g1t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
         # the column sums of g1 (= the proj bias gradient) come out of the same pass
@@ -234,20 +234,21 @@ class LayerFn(Function):
         if g1t is None:
             g1t = g1
         # ---- attention
-        with on_side(dev, g1t, sv['ctxv']):
-            _wgrad(g1t, sv['ctxv'], E, E, M, E, E, store.grad_phys(wo), code)
         dctx = torch.empty(M, E, device=dev, dtype=T)
         K.gemm(g1t, store.shadow(wo), M, E, E, E, E, code, b_mode=K.OP_K, out_t=dctx, ldo_t=E)
         dqkv = torch.empty(M, 3 * E, device=dev, dtype=T)
         delta = torch.empty(Bn, H, N, device=dev)
         K.attention_bwd(sv['qkv'], sv['ctxv'], dctx, sv['lse'], delta, dqkv, Bn, N, H, code, bias_u=sv['bias_u'],
                         row_flag=sv['row_flag'], bias_w=bias_w)
-        with on_side(dev, dqkv, sv['xn']):
-            _wgrad(dqkv, sv['xn'], 3 * E, E, M, 3 * E, E, store.grad_phys(wqkv), code)
+        with on_side(dev, dqkv, xn, dz, xn2, g1t, ctxv, g2t, a_act):
+            K.wgrad_grouped([(dz, xn2, F_, E, M, store.grad_phys(w1)),
+                             (g2t, a_act, E, F_, M, store.grad_phys(w2)),
+                             (dqkv, xn, 3 * E, E, M, store.grad_phys(wqkv)),
+                             (g1t, ctxv, E, E, M, store.grad_phys(wo))], code)
             K.colsum(dqkv, 3 * E, M, 3 * E, store.grad_phys(bqkv), code)
         dxn = torch.empty(M, E, device=dev, dtype=T)
         K.gemm(dqkv, store.shadow(wqkv), M, E, 3 * E, 3 * E, E, code, b_mode=K.OP_K, out_t=dxn, ldo_t=E)
-        del dqkv
+        del dqkv, dz
         g0 = torch.empty(Bn, N, E, device=dev)
         g0t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
         g0cs = torch.zeros(E, device=dev)

@@ -11,7 +11,7 @@ from . import _lib as L
 from ._lib import (ACT_GELU, ACT_GELU_BWD, ACT_NONE, BF16, F32, OP_K, OP_K_CONV, OP_K_TAPSPLIT, OP_ROW,
                    OP_ROW_CONV, S4FError, call, p, stream)
 
-__all__ = ['gemm', 'cast', 'cast_back', 'im2col_patch16', 'cls_pos', 'tokens_bwd', 'colsum', 'layernorm_fwd',
+__all__ = ['gemm', 'wgrad_grouped', 'cast', 'cast_back', 'im2col_patch16', 'cls_pos', 'tokens_bwd', 'colsum', 'layernorm_fwd',
            'layernorm_bwd', 'add_f32', 'attention_fwd', 'attention_bwd', 'bn_stats', 'bn_finalize',
            'bn_relu_up_fwd', 'bn_relu_up_bwd', 'bn_bwd_apply', 'bn_param_grads', 'upce_fwd', 'upce_bwd',
            'up_pseudo_label', 'up_logits_nchw', 'ce_fwd', 'ce_bwd', 'ema', 'sgd_momentum']
@@ -160,7 +160,59 @@ def _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, re
     d.act, d.atomic = act, 1 if atomic else 0
     d.pos_period, d.pos = pos_period, p(pos)
     d.tile_hint = tile_hint
+    if _collect is not None:
+        _collect.append(d)
+        return
     call('s4f_gemm', ctypes.byref(d), stream(), tag=(a_mode, b_mode, M, N, K))
+
+
+_collect = None
+
+
+def _t256(M, N):
+    return -(-M // 256) * -(-N // 256)
+
+
+def wgrad_grouped(problems, dtype):
+    """problems: up to 4 tuples (dy[rows, M], x[rows, N], M, N, rows, out fp32 [M, N]); out += dy^T x for each.  One
+    launch for all of them in bf16 (s4f_gemm_grouped); the (tile variant, split-K) pair is tuned once per group."""
+    global _collect
+    if not 1 <= len(problems) <= 4:
+        raise S4FError('wgrad_grouped: 1..4 problems')
+    rows = problems[0][4]
+    same_rows = all(pr[4] == rows for pr in problems)
+    # profiler tag: one equivalent problem (sum of M*N, shared row count) so that 2MNK stays the exact flop count
+    tag = (OP_K, OP_K, sum(pr[2] * pr[3] for pr in problems), 1, rows) if same_rows else None
+
+    def launch(hint, sk, outs):
+        global _collect
+        _collect = []
+        try:
+            for (dy, x, M, N, R, _), out in zip(problems, outs):
+                _gemm_launch(dy, x, M, N, R, M, N, dtype, OP_K, OP_K, 1.0, None, None, 0, out, N, None, 0, None, 0, None, 0,
+                             ACT_NONE, True, sk, None, 0, None, hint)
+            descs = _collect
+        finally:
+            _collect = None
+        arr = (L.GemmDesc * len(descs))(*descs)
+        call('s4f_gemm_grouped', arr, len(descs), stream(), tag=tag)
+
+    outs = [pr[5] for pr in problems]
+    tiles = sum(_t256(pr[2], pr[3]) for pr in problems)
+    base = max(1, round(256 / tiles))
+    if dtype != BF16:
+        return launch(0, base, outs)                 # fp32 parity mode: the C side runs the problems one by one
+    if not AUTOTUNE:
+        return launch(4, base, outs)
+    sig = ('wgrad_grouped',) + tuple((pr[2], pr[3], pr[4]) for pr in problems)
+    choice = _TUNED.get(sig)
+    if choice is None and L._prof is not None:
+        choice = (4, base)
+    if choice is None:
+        tmps = [torch.empty_like(o) for o in outs]
+        sks = sorted({base, base * 2, base * 3, base * 4, max(1, base // 2)})
+        choice = _tune_gemm(sig, lambda h, sk: launch(h, sk, tmps), [(h, sk) for h in (2, 3, 4) for sk in sks])
+    launch(choice[0], choice[1], outs)
 
 
 def cast(src, dst, dtype):

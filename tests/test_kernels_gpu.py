@@ -526,6 +526,34 @@ def test_gemm2_dense_modes(K, hint):
     assert float(o21[:, 21:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('code', DTYPES)
+def test_wgrad_grouped(K, code, monkeypatch):
+    """the four weight-gradient GEMMs of an encoder layer in one launch (bf16) == four separate ones"""
+    rows = 1100
+    shapes = [(768, 256), (256, 768), (512, 256), (256, 256)]      # (M, N): different tile counts per problem
+    probs, refs, prods = [], [], []
+    for i, (M, N) in enumerate(shapes):
+        dy, x = q(rnd(rows, M, seed=10 + i), code), q(rnd(rows, N, seed=20 + i), code)
+        base = rnd(M, N, seed=30 + i)
+        out = dev(base.clone())
+        probs.append((dev(dy, code), dev(x, code), M, N, rows, out))
+        prods.append(dy.t() @ x)
+        refs.append(base + prods[-1])
+    K.wgrad_grouped(probs, code)                        # autotuned (bf16) / sequential (fp32)
+    for pr, ref, (M, N) in zip(probs, refs, shapes):
+        check(pr[5], ref, code, f'grouped wgrad {M}x{N}')
+    if code == 1:
+        # every (tile variant, split-K) the tuner may choose, incl. more splits than a problem has k-steps
+        import s4former_amd.kernels as KK
+        for hint in (2, 3, 4):
+            for sk in (1, 3, 40):
+                monkeypatch.setattr(KK, '_TUNED', {('wgrad_grouped',) + tuple((M, N, rows) for (M, N) in shapes): (hint, sk)})
+                outs = [dev(torch.zeros(M, N)) for (M, N) in shapes]
+                K.wgrad_grouped([(pr[0], pr[1], pr[2], pr[3], rows, o) for pr, o in zip(probs, outs)], code)
+                for o, ref, (M, N) in zip(outs, prods, shapes):
+                    check(o, ref, code, f'grouped wgrad hint {hint} sk {sk} {M}x{N}')
+
+
 @pytest.mark.parametrize('hint', [2, 3, 4, 5, 6])
 @pytest.mark.parametrize('Cin,Cout', [(768, 256), (256, 256)])
 def test_gemm2_conv_modes(K, hint, Cin, Cout):
