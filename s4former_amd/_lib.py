@@ -171,5 +171,13 @@ def p(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_cur_device = getattr(torch._C, '_cuda_getDevice', None)
+
+
 def stream():
+    """raw hipStream_t of torch's current stream (the C entry points: torch.cuda.current_stream() costs ~9 us per call
+    on the host, this ~0.3 us; the step makes ~700 launches)"""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream

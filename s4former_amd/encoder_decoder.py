@@ -349,12 +349,17 @@ class EncoderDecoder(BaseSegmentor):
         timg = teacher_data['img']
         if tidx != list(range(len(tidx))):
             timg = timg[torch.tensor(tidx, device=timg.device)]
+        if not self.ema:
+            raise S4FError('the teacher of this build is the EMA model (ema=True in all three SETR configs)')
         with torch.no_grad():
-            self.set_eval(self.ema)
-            if not self.ema:
-                raise S4FError('the teacher of this build is the EMA model (ema=True in all three SETR configs)')
-            teacher_info = self.extract_teacher_info_ema(timg, [teacher_data['img_metas'][i] for i in tidx])
-            self.set_train(self.ema)
+            # The reference switches the EMA modules to eval() around this call (encoder_decoder.py:520-524, 586).  The only
+            # mode-dependent op of the teacher is the head's BatchNorm, so the same effect is had by an override flag
+            # on that head instead of two walks over ~400 modules per step; module.training is what it was before.
+            self.decode_head_ema._eval_override = True
+            try:
+                teacher_info = self.extract_teacher_info_ema(timg, [teacher_data['img_metas'][i] for i in tidx])
+            finally:
+                self.decode_head_ema._eval_override = False
         return teacher_info
 
     def _fused_step(self, data_groups):

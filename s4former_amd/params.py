@@ -23,7 +23,7 @@ def _is_conv3x3(t):
 
 
 class _Entry:
-    __slots__ = ('module', 'attr', 'is_param', 'name', 'group', 'shape', 'numel', 'off', 'cl')
+    __slots__ = ('module', 'attr', 'is_param', 'name', 'group', 'shape', 'numel', 'off', 'cl', 'v_phys', 'v_grad', 'v_shadow')
 
 
 class ParamStore:
@@ -114,6 +114,13 @@ class ParamStore:
             else:
                 e.module._buffers[e.attr] = v
                 self.by_id[id(v)] = e
+        # per-entry physical views, made once (slicing costs a few host microseconds and the step asks ~300 times)
+        for e in self.entries:
+            e.v_phys = flat[e.off:e.off + e.numel]
+            e.v_grad = self.grad[e.off:e.off + e.numel] if self.grad is not None else None
+            src = self.flat_t if self.flat_t is not None else flat
+            e.v_shadow = src[e.off:e.off + e.numel]
+        self.generation = getattr(self, 'generation', 0) + 1
         self._shadow_dirty = True
         self._versions = None
         self.first_sgd_step = True
@@ -160,18 +167,14 @@ class ParamStore:
 
     def phys(self, t):
         """fp32 physical (contiguous) view of a parameter/buffer"""
-        e = self.entry(t)
-        return self.flat[e.off:e.off + e.numel]
+        return self.entry(t).v_phys
 
     def grad_phys(self, t):
-        e = self.entry(t)
-        return self.grad[e.off:e.off + e.numel]
+        return self.entry(t).v_grad
 
     def shadow(self, t):
         """operand-typed physical view (bf16 shadow arena in perf mode, the fp32 master in parity mode)"""
-        e = self.entry(t)
-        src = self.flat_t if self.flat_t is not None else self.flat
-        return src[e.off:e.off + e.numel]
+        return self.entry(t).v_shadow
 
     # ------------------------------------------------------------------ shadow maintenance
     def _version_sum(self):

@@ -148,6 +148,19 @@ class SETRUPHead(BaseDecodeHead):
         return self._store
 
     def _hp(self, grid):
+        """parameter / buffer / config bundle of the fused head node; cached per (grid, mode, arena generation): the
+        Parameter objects are stable, the BN buffers are re-pointed whenever the ParamStore rebuilds its arena"""
+        training = self.training and not getattr(self, '_eval_override', False)
+        key = (grid, training, getattr(self._store, 'generation', None))
+        cache = self.__dict__.setdefault('_hp_cache', {})
+        hp = cache.get(key)
+        if hp is None:
+            if len(cache) > 8:
+                cache.clear()
+            hp = cache[key] = self._build_hp(grid, training)
+        return hp
+
+    def _build_hp(self, grid, training):
         convs = []
         for k, seq in enumerate(self.up_convs):
             cm = seq[0]
@@ -157,9 +170,16 @@ class SETRUPHead(BaseDecodeHead):
         return dict(grid=grid, norm_w=self.norm.weight, norm_b=self.norm.bias, ln_eps=self.norm.eps, convs=convs,
                     seg_w=self.conv_seg.weight, seg_b=self.conv_seg.bias, num_classes=self.num_classes,
                     up_scale=self.up_scale, bn_eps=cm0.bn.eps, bn_momentum=cm0.bn.momentum, sync_bn=cm0.sync,
-                    ignore_index=self.ignore_index, training=self.training)
+                    ignore_index=self.ignore_index, training=training)
 
     def _params(self):
+        ps = self.__dict__.get('_params_cache')
+        if ps is not None and ps[0] is self.norm.weight:
+            return ps
+        ps = self.__dict__['_params_cache'] = self._build_params()
+        return ps
+
+    def _build_params(self):
         ps = [self.norm.weight, self.norm.bias]
         for seq in self.up_convs:
             cm = seq[0]
@@ -189,7 +209,7 @@ class SETRUPHead(BaseDecodeHead):
         store = self._ensure_store(x.device)
         tokens, grid = self._tokens_of(x)
         with torch.no_grad():
-            logits, (Bn, h, w), _ = head_forward(tokens.detach(), self._hp(grid), store, training=self.training, save=False)
+            logits, (Bn, h, w), _ = head_forward(tokens.detach(), (hp := self._hp(grid)), store, training=hp['training'], save=False)
             s = self.up_scale
             out = torch.empty(Bn, self.num_classes, h * s, w * s, device=x.device, dtype=torch.float32)
             K.up_logits_nchw(logits, out, Bn, h, w, self.num_classes, LOGIT_LD, s)
@@ -201,7 +221,7 @@ class SETRUPHead(BaseDecodeHead):
         store = self._ensure_store(x.device)
         tokens, grid = self._tokens_of(x)
         with torch.no_grad():
-            logits, geom, _ = head_forward(tokens.detach(), self._hp(grid), store, training=self.training, save=False)
+            logits, geom, _ = head_forward(tokens.detach(), (hp := self._hp(grid)), store, training=hp['training'], save=False)
         return logits, geom
 
     def fused_loss(self, inputs, labels_u8, loss_weight):

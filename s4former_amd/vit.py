@@ -111,6 +111,12 @@ class TransformerEncoderLayer(BaseModule):
         return self.ln2
 
     def _params(self):
+        ps = self.__dict__.get('_params_cache')
+        if ps is None or ps[0] is not self.ln1.weight:
+            ps = self.__dict__['_params_cache'] = self._build_params()
+        return ps
+
+    def _build_params(self):
         a, f = self.attn.attn, self.ffn.layers
         return (self.ln1.weight, self.ln1.bias, a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias,
                 self.ln2.weight, self.ln2.bias, f[0][0].weight, f[0][0].bias, f[1].weight, f[1].bias)
