@@ -168,6 +168,12 @@ def main():
         opt.step(grad_scale=reducer.grad_scale())
         return out
 
+    # The critical chain (forward, input gradients, optimizer) runs on a high-priority HIP stream; the weight-gradient
+    # GEMMs of functional.py's side stream (priority 0) then only take the CUs the chain leaves idle.
+    main = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('S4F_MAIN_PRIORITY', '1') != '0' else None
+    if main is not None:
+        main.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(main)
     it = 0
     for _ in range(args.warmup):
         out = step(it)

@@ -66,12 +66,9 @@ class GradReducer:
         if self._stream is None:
             self._stream = torch.cuda.Stream()
         self._stream.wait_stream(torch.cuda.current_stream())
-        try:
-            from .functional import _side
-            for st in _side.values():
-                self._stream.wait_stream(st)          # weight-gradient kernels run on the compute side stream
-        except ImportError:
-            pass
+        from .functional import extra_streams
+        for st in extra_streams():
+            self._stream.wait_stream(st)              # weight-gradient kernels / heads run on their own streams
         return torch.cuda.stream(self._stream)
 
     def _launch(self, t):

@@ -20,7 +20,7 @@ from . import kernels as K
 from . import runtime
 from ._lib import S4FError
 from .base_module import BaseModule
-from .functional import LOGIT_LD
+from .functional import LOGIT_LD, join_side_streams, on_head_stream
 from .params import ParamStore
 from .registry import SEGMENTORS, build_backbone, build_head, build_neck
 
@@ -265,16 +265,20 @@ class EncoderDecoder(BaseSegmentor):
     def extract_feat_ema(self, img):
         return self.backbone_ema(img)
 
+    # The decode head (both of its calls: BN statistics and parameter gradients of one head stay ordered) and the
+    # auxiliary heads run on two extra HIP streams; forward_train joins them before it returns the losses.
     def _decode_head_forward_train(self, x, img_metas, gt_semantic_seg):
-        return add_prefix(self.decode_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), 'decode')
+        with on_head_stream(gt_semantic_seg.device, 'decode'):
+            return add_prefix(self.decode_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), 'decode')
 
     def _auxiliary_head_forward_train(self, x, img_metas, gt_semantic_seg):
         losses = dict()
-        if isinstance(self.auxiliary_head, nn.ModuleList):
-            for idx, aux_head in enumerate(self.auxiliary_head):
-                losses.update(add_prefix(aux_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), f'aux_{idx}'))
-        else:
-            losses.update(add_prefix(self.auxiliary_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), 'aux'))
+        with on_head_stream(gt_semantic_seg.device, 'aux'):
+            if isinstance(self.auxiliary_head, nn.ModuleList):
+                for idx, aux_head in enumerate(self.auxiliary_head):
+                    losses.update(add_prefix(aux_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), f'aux_{idx}'))
+            else:
+                losses.update(add_prefix(self.auxiliary_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), 'aux'))
         return losses
 
     # ------------------------------------------------------------------ EMA
@@ -298,6 +302,15 @@ class EncoderDecoder(BaseSegmentor):
     # ------------------------------------------------------------------ training
     def forward_train(self, img, img_metas, **kwargs):
         """encoder_decoder.py:386-514"""
+        losses = self._forward_train(img, img_metas, **kwargs)
+        join_side_streams()                       # head streams -> caller's stream; the loss scalars are read there
+        cur = torch.cuda.current_stream()
+        for v in list(losses.values()) + [getattr(self, 'last_mask_ratio', None)]:
+            if isinstance(v, torch.Tensor) and v.is_cuda:
+                v.record_stream(cur)
+        return losses
+
+    def _forward_train(self, img, img_metas, **kwargs):
         if not img.is_cuda:
             raise S4FError('the S4Former step runs on the MI355X HIP kernels only: move model and batch to the GPU')
         self.ensure_engine(img.device)
@@ -332,9 +345,9 @@ class EncoderDecoder(BaseSegmentor):
             self.losses.update(loss_decode_sup)
 
         if do_unsup:
-            unsup_loss = weighted_loss(
-                self.foward_unsup_train(data_groups['unsup_teacher'], data_groups['unsup_student'], sup_imgs, sup_gts),
-                weight=self.unsup_weight)
+            unsup_raw = self.foward_unsup_train(data_groups['unsup_teacher'], data_groups['unsup_student'], sup_imgs, sup_gts)
+            with on_head_stream(img.device, 'decode'):
+                unsup_loss = weighted_loss(unsup_raw, weight=self.unsup_weight)
             if self.iter_unsup_start != 0:
                 if self.current_iter > self.iter_unsup_start:
                     self.losses.update(unsup_loss)
@@ -394,15 +407,17 @@ class EncoderDecoder(BaseSegmentor):
         if self.with_auxiliary_head:
             self.losses.update(self._auxiliary_head_forward_train(f_sup, sup['img_metas'], sup['gt_semantic_seg']))
         self.losses.update(loss_decode_sup)
-        # unsupervised heads (same order of head calls as the reference: sup, masked-unsup, plain-unsup)
-        loss_unsup = {}
-        student_info = dict(img=simg, img_metas=stu['img_metas'], backbone_feature=f_mask)
-        if self.attn_mask_seperate_head:
-            loss_unsup['loss_seg_unsup_attn_mask'] = self.compute_pseudo_loss(student_info, teacher_info)['loss_seg_unsup'] * 0.5
-            student_info['backbone_feature'] = self.backbone.split_taps(outs, ns + nu, ns + 2 * nu)
-        losses = self.compute_pseudo_loss(student_info, teacher_info)
-        loss_unsup['loss_seg_unsup'] = losses['loss_seg_unsup'] * self.fdrop_loss_weight
-        unsup_loss = weighted_loss(loss_unsup, weight=self.unsup_weight)
+        # unsupervised heads (same order of head calls as the reference: sup, masked-unsup, plain-unsup); the loss
+        # scalings stay on the decode head's stream with the losses they scale
+        with on_head_stream(simg.device, 'decode'):
+            loss_unsup = {}
+            student_info = dict(img=simg, img_metas=stu['img_metas'], backbone_feature=f_mask)
+            if self.attn_mask_seperate_head:
+                loss_unsup['loss_seg_unsup_attn_mask'] = self.compute_pseudo_loss(student_info, teacher_info)['loss_seg_unsup'] * 0.5
+                student_info['backbone_feature'] = self.backbone.split_taps(outs, ns + nu, ns + 2 * nu)
+            losses = self.compute_pseudo_loss(student_info, teacher_info)
+            loss_unsup['loss_seg_unsup'] = losses['loss_seg_unsup'] * self.fdrop_loss_weight
+            unsup_loss = weighted_loss(loss_unsup, weight=self.unsup_weight)
         if self.iter_unsup_start != 0:
             if self.current_iter > self.iter_unsup_start:
                 self.losses.update(unsup_loss)
@@ -428,7 +443,8 @@ class EncoderDecoder(BaseSegmentor):
             feat = self.extract_feat(student_info['img'], attn_mask=attn_mask, attn_mask_weight=self.attn_mask_weight,
                                      adaptive_attn_mask=self.adaptive_attn_mask)
             student_info['backbone_feature'] = feat
-            loss_unsup['loss_seg_unsup_attn_mask'] = self.compute_pseudo_loss(student_info, teacher_info)['loss_seg_unsup'] * 0.5
+            with on_head_stream(feat[-1].device, 'decode'):      # the scaling stays on the stream of the loss it scales
+                loss_unsup['loss_seg_unsup_attn_mask'] = self.compute_pseudo_loss(student_info, teacher_info)['loss_seg_unsup'] * 0.5
             feat = self.extract_feat(student_info['img'])
             student_info['backbone_feature'] = feat
         elif self.plain_mt_pseudo_loss:
@@ -442,8 +458,9 @@ class EncoderDecoder(BaseSegmentor):
             return loss_unsup
 
         if self.attn_mask_seperate_head or self.plain_mt_pseudo_loss:
-            losses = self.compute_pseudo_loss(student_info, teacher_info)
-            loss_unsup['loss_seg_unsup'] = losses['loss_seg_unsup'] * self.fdrop_loss_weight
+            with on_head_stream(student_info['img'].device, 'decode'):
+                losses = self.compute_pseudo_loss(student_info, teacher_info)
+                loss_unsup['loss_seg_unsup'] = losses['loss_seg_unsup'] * self.fdrop_loss_weight
         return loss_unsup
 
     def extract_teacher_info_ema(self, img, img_metas, unsup_confidence=None):
@@ -463,10 +480,11 @@ class EncoderDecoder(BaseSegmentor):
     def compute_pseudo_loss(self, student_info, teacher_info):
         """encoder_decoder.py:906-934 (hard labels): mean over ALL pixels of CE(student logits, pseudo labels with
         ignore 255); mask_ratio = sum(conf) / numel (kept on the device in self.last_mask_ratio)."""
-        loss = self.decode_head.fused_loss(student_info['backbone_feature'], teacher_info['hard_seg_label'], 1.0)
-        out = {'loss_seg_unsup': loss}
-        if self.unsup_confidence != 0:
-            numel = teacher_info['hard_seg_label'].numel()
-            self.last_mask_ratio = teacher_info['conf_count'].to(torch.float32) / numel
-            out['mask_ratio'] = self.last_mask_ratio
+        with on_head_stream(teacher_info['hard_seg_label'].device, 'decode'):
+            loss = self.decode_head.fused_loss(student_info['backbone_feature'], teacher_info['hard_seg_label'], 1.0)
+            out = {'loss_seg_unsup': loss}
+            if self.unsup_confidence != 0:
+                numel = teacher_info['hard_seg_label'].numel()
+                self.last_mask_ratio = teacher_info['conf_count'].to(torch.float32) / numel
+                out['mask_ratio'] = self.last_mask_ratio
         return out

@@ -36,12 +36,63 @@ def side_stream(device):
     return _side[key]
 
 
+_head = {}                     # (device index, name) -> stream the decode / auxiliary heads run on
+GRAD_CONSUMER = None           # stream that consumes the token gradients of a head launched on a head stream
+USE_HEAD_STREAMS = os.environ.get('S4F_HEAD_STREAMS', '1') != '0'
+
+
+def head_stream(device, name, priority=0):
+    key = (torch.device(device).index, name)
+    if key not in _head:
+        _head[key] = torch.cuda.Stream(device=device, priority=priority)
+    return _head[key]
+
+
+def extra_streams(device=None):
+    """every stream besides the caller's that this package launches compute kernels on"""
+    idx = None if device is None else torch.device(device).index
+    return [st for st in list(_side.values()) + list(_head.values()) if idx is None or st.device.index == idx]
+
+
 def join_side_streams():
-    """make the current stream wait for everything enqueued on the side stream(s)"""
+    """make the current stream wait for everything enqueued on the side / head stream(s)"""
     cur = torch.cuda.current_stream()
-    for st in _side.values():
-        if st.device == cur.device:
-            cur.wait_stream(st)
+    for st in extra_streams(cur.device):
+        cur.wait_stream(st)
+
+
+class on_head_stream:
+    """with on_head_stream(dev, name): the head's forward (and therefore, by autograd's stream rule, its backward) runs on
+    its own stream after everything enqueued so far.  The decode head and the auxiliary heads are independent given the
+    backbone taps; their HBM-bound BN / upsample kernels then overlap the other head's conv GEMMs."""
+
+    def __init__(self, device, name):
+        self.dev, self.name = device, name
+        self.on = USE_HEAD_STREAMS and torch.device(device).type == 'cuda'
+
+    def __enter__(self):
+        global GRAD_CONSUMER
+        if not self.on:
+            return self
+        main = torch.cuda.current_stream()
+        if any(main == st for st in _head.values()):
+            self.on = False                       # already on a head stream (nested use): stay there
+            return self
+        self.st = head_stream(self.dev, self.name, main.priority)
+        self.st.wait_stream(main)
+        self.prev_consumer = GRAD_CONSUMER
+        GRAD_CONSUMER = main
+        self.ctx = torch.cuda.stream(self.st)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        global GRAD_CONSUMER
+        if not self.on:
+            return False
+        self.ctx.__exit__(*exc)
+        GRAD_CONSUMER = self.prev_consumer
+        return False
 
 
 class on_side:
@@ -414,6 +465,7 @@ class HeadLossFn(Function):
             ctx.sv, ctx.hp, ctx.store = sv, hp, store
             ctx.meta = (labels_u8, k, Bn, h, w, s)
             ctx.lse = lse
+            ctx.consumer = GRAD_CONSUMER
         return (loss_sum * k).reshape(())
 
     @staticmethod
@@ -429,6 +481,8 @@ class HeadLossFn(Function):
                    gscale_dev=gdev, lse=ctx.lse)
         ctx.lse = None
         dtok = head_backward(dlo, dlo_t if dlo_t is not None else dlo, sv, hp, store)
+        if ctx.consumer is not None:
+            dtok.record_stream(ctx.consumer)          # allocated on the head's stream, read by the backbone's
         ctx.sv = None
         store.node_done()
         return (dtok, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
