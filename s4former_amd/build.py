@@ -13,10 +13,14 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 OBJ_DIR = os.path.join(CSRC, '_obj')
 LIB_PATH = os.path.join(PKG_DIR, 'libs4f_hip.so')
-SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm3.hip', 'attention.hip', 'elementwise.hip', 'head.hip']
+SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm3.hip', 'gemm4.hip', 'attention.hip', 'elementwise.hip', 'head.hip']
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 's4f.h')]
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off',
-         '-Wno-unused-result', '-Wno-unused-value', '-mllvm', '-amdgpu-mfma-vgpr-form=1']
+BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off',
+              '-Wno-unused-result', '-Wno-unused-value']
+FLAGS = BASE_FLAGS + ['-mllvm', '-amdgpu-mfma-vgpr-form=1']
+# per-file overrides: gemm4.hip keeps its 256 accumulators per lane in AGPRs (no vgpr-form); it #includes gemm2.hip
+FILE_FLAGS = {'gemm4.hip': BASE_FLAGS}
+FILE_DEPS = {'gemm4.hip': ['gemm2.hip']}
 
 
 def _hipcc():
@@ -44,15 +48,17 @@ def build_library(verbose=False, force=False):
     objs = []
     for src in SOURCES:
         sp = os.path.join(CSRC, src)
-        tag = _digest([sp] + hdrs, FLAGS)
+        flags = FILE_FLAGS.get(src, FLAGS)
+        deps = [os.path.join(CSRC, x) for x in FILE_DEPS.get(src, [])]
+        tag = _digest([sp] + deps + hdrs, flags)
         obj = os.path.join(OBJ_DIR, f'{os.path.splitext(src)[0]}.{tag}.o')
         objs.append(obj)
         if force or not os.path.exists(obj):
-            jobs.append((sp, obj))
+            jobs.append((sp, obj, flags))
 
     def compile_one(job):
-        sp, obj = job
-        cmd = [hipcc] + FLAGS + ['-c', sp, '-o', obj]
+        sp, obj, flags = job
+        cmd = [hipcc] + flags + ['-c', sp, '-o', obj]
         if verbose:
             print(' '.join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

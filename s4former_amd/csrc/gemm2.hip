@@ -13,7 +13,10 @@
 #include "common.h"
 #include "../../include/s4f.h"
 
-namespace g2 {
+#ifndef G2_NS
+#define G2_NS g2
+#endif
+namespace G2_NS {
 
 __device__ __attribute__((aligned(64))) char g_zero_page[64];
 
@@ -581,7 +584,9 @@ int dispatch(const s4f_gemm_desc& d, hipStream_t st) {
   return -100;
 }
 
-}  // namespace g2
+}  // namespace G2_NS
+
+#ifndef G2_VARIANT_ONLY
 
 // entry used by s4f_gemm (gemm.hip) for bf16 problems: returns -100 when the shape should stay on the 128x128 kernel
 int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn) {
@@ -602,3 +607,4 @@ int s4f_gemm2_grouped_try(const s4f_gemm_desc* ds, int count, hipStream_t st) {
     default: return -100;
   }
 }
+#endif  // G2_VARIANT_ONLY

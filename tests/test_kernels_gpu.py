@@ -489,7 +489,7 @@ def test_ema_sgd(K, code):
 
 
 # ------------------------------------------------------------------------------------------------ 256-row LDS-DMA kernel
-@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6])
+@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6, 7])
 def test_gemm2_dense_modes(K, hint):
     code = 1
     M, N, K_ = 1000, 768, 832
@@ -554,7 +554,7 @@ def test_wgrad_grouped(K, code, monkeypatch):
                     check(o, ref, code, f'grouped wgrad hint {hint} sk {sk} {M}x{N}')
 
 
-@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6])
+@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize('Cin,Cout', [(768, 256), (256, 256)])
 def test_gemm2_conv_modes(K, hint, Cin, Cout):
     code = 1
