@@ -80,7 +80,9 @@ typedef struct s4f_gemm_desc {
   const float* pos;         /* fp32 [pos_period, N] or NULL */
   /* kernel selection: 0 = automatic; 1 = 128x128 register-staged kernel; 2 = 256x128 LDS-DMA kernel;
    * 3 = 256x256 LDS-DMA kernel, 8 waves; 4 = 256x256, 16 waves; 5 = 256x256, 16 waves, K step 32, 4-stage ring
-   * with counted waits (2-5: bf16 only) */
+   * with counted waits; 6 = 8 waves, K step 32; 7 = 4 waves (AGPR accumulators); 8 / 9 = 256x192 tile, 16 / 8 waves
+   * (row-major A with row- or k-major B only: N = 768 / 2304 of the token GEMMs).  2-9: bf16 only.  In the kernels of
+   * hints 3, 4, 8, 9 a row remainder M % 256 of at most 16 rows (one cls row per image) is folded into the last tile row. */
   int32_t tile_hint;
 } s4f_gemm_desc;
 

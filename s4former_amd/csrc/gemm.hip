@@ -334,6 +334,7 @@ static int pick_tile(const s4f_gemm_desc& d) {
   if (d.tile_hint == 3 || d.tile_hint == 4) return 256;
   if (d.tile_hint == 5 || d.tile_hint == 6) return 512;
   if (d.tile_hint == 7) return 1024;
+  if (d.tile_hint == 8 || d.tile_hint == 9) return 192;     // 256 x 192 tile, 16 / 8 waves (token GEMMs with N = 768, 2304)
   const long sk = d.splitk < 1 ? 1 : d.splitk;
   const long t256 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 256) * sk;
   const long t128 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 128) * sk;

@@ -1,5 +1,5 @@
 // Fast bf16 path of the GEMM family (same operand modes and epilogues as gemm.hip): 256 x BN block tile
-// (BN = 128 | 256), 8 waves (4 x 2), wave tile 64 x BN/2, K step 64, operands streamed global -> LDS by
+// (BN = 128 | 192 | 256), 8 or 16 waves (4 x 2 | 4 x 4), K step 64, operands streamed global -> LDS by
 // global_load_lds_dwordx4 (LDS-DMA, no staging registers) into a 2-deep LDS ring, one barrier per K step
 // (guide §5 "glds, 2 LDS buffers, BK=64, vmcnt(0) + plain __syncthreads()").
 //
@@ -10,6 +10,13 @@
 //       groups are spaced 1024 + PAD bytes apart and chunk c of row r (in group) sits at c ^ (2 r), so that the
 //       8 k-rows one half-wave touches in a ds_read_b64_tr_b16 fall in 8 distinct 32-B bank slots.
 // Rows / chunks outside the problem (M, N, K edges, conv zero padding) are fetched from a zero page.
+//
+// Tile-count quantisation (the token GEMMs have M = B * 1025: 64 full tile rows + one cls row per image):
+//   * BN = 192 gives N = 768 / 2304 exactly 4 / 12 tile columns (256 / 768 tiles for 256 CUs at M = 16384); its
+//     k-major B image keeps the 256-column geometry with the last 64 columns masked to the zero page.
+//   * a row remainder of at most 16 rows is FOLDED into the last tile row instead of opening a 65th one: those
+//     blocks stream a 16-row "tail" image next to the A tile and every wave owns the 16 x 16 tail sub-tiles
+//     j = wm (mod 4) of its column range (one or two extra MFMAs per 32-deep step).
 #include "common.h"
 #include "../../include/s4f.h"
 
@@ -25,9 +32,11 @@ struct GemmArgs {
   int nk;
   int nk_per_split;
   int tiles_m, tiles_n;
+  int tail_rows;                                   // rows folded into the last tile row (0: none)
 };
 
 constexpr int BM = 256, BK = 64;
+constexpr int TAIL_MAX = 16, TAIL_BYTES = TAIL_MAX * 128;
 
 template <int COLS> struct KImg {                 // k-major image geometry for COLS columns of bf16
   static constexpr int RB = COLS * 2;             // row bytes: 512 / 256
@@ -51,11 +60,14 @@ __device__ __forceinline__ void glds16(const void* src, char* lds_wave_base) {
 // One feeder per operand: NSLOT DMA slots per thread per k-iteration.  All per-slot address arithmetic is
 // incremental: a slot keeps a byte pointer that advances by a constant per k-iteration; the conv modes
 // recompute it only when the tap changes (a wave-uniform branch every cC/64 iterations).
-template <int MODE, bool IS_A, int EXT, int NW>   // EXT = rows (row-major) or columns (k-major) of the tile
+// EXT = rows (row-major) or columns (k-major) of the LDS image; VALID <= EXT = columns of a k-major tile that belong
+// to the block (the rest is masked to the zero page: BN = 192 in the 256-column geometry)
+template <int MODE, bool IS_A, int EXT, int NW, int VALID = EXT>
 struct Feeder {
   static constexpr bool KM = (MODE == S4F_OP_K || MODE == S4F_OP_K_TAPSPLIT || MODE == S4F_OP_K_CONV);
   static constexpr int NG = KM ? KImg<EXT>::NG : RImg<EXT>::NG;
-  static constexpr int NSLOT = NG / NW;
+  static constexpr int NSLOT = (NG + NW - 1) / NW;
+  static constexpr bool RAGGED = (NG % NW) != 0;   // the last slot exists only for waves < NG % NW
   static constexpr int BYTES = KM ? KImg<EXT>::BYTES : RImg<EXT>::BYTES;
   static constexpr int GSTRIDE = KM ? KImg<EXT>::GS : 1024;
 
@@ -124,7 +136,7 @@ struct Feeder {
         srcchunk[u] = cprime ^ (2 * r);
         krow[u] = G::R * t + r;
         const int col = idx0 + srcchunk[u] * 8;
-        kend[u] = (col < lim && krow[u] < K) ? (K - krow[u] + BK - 1) / BK : 0;
+        kend[u] = (col < lim && srcchunk[u] * 8 < VALID && krow[u] < K) ? (K - krow[u] + BK - 1) / BK : 0;
         step = (long)BK * ld * 2;
         if constexpr (MODE == S4F_OP_K) {
           cur[u] = base + ((long)(k0 + krow[u]) * ld + col) * 2;
@@ -146,6 +158,7 @@ struct Feeder {
 #pragma unroll
     for (int u = 0; u < NSLOT; ++u) {
       const int t = wave + NW * u;
+      if (RAGGED && t >= NG) break;                  // wave-uniform
       char* dst = img + t * GSTRIDE;
       const char* src;
       if constexpr (MODE == S4F_OP_K_CONV) {
@@ -232,13 +245,17 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, c
   constexpr bool AK = (AMODE == S4F_OP_K);
   constexpr bool BKM = (BMODE == S4F_OP_K || BMODE == S4F_OP_K_TAPSPLIT || BMODE == S4F_OP_K_CONV);
   constexpr bool TRMAP = AK || BKM;
+  constexpr int BGEO = (BKM && BN == 192) ? 256 : BN;   // k-major 192-column tiles live in the 256-column image
   using FA = Feeder<AMODE, true, BM, NW>;
-  using FB = Feeder<BMODE, false, BN, NW>;
+  using FB = Feeder<BMODE, false, BGEO, NW, BN>;
+  constexpr bool CAN_TAIL = (AMODE == S4F_OP_ROW) && !(NW == 8 && BN == 128);
   constexpr int A_BYTES = FA::BYTES, B_BYTES = FB::BYTES;
-  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int STAGE = A_BYTES + B_BYTES + (CAN_TAIL ? TAIL_BYTES : 0);
+  constexpr int T_OFF = A_BYTES + B_BYTES;          // tail image inside a stage
   constexpr int WN = NW / 4;                        // waves along N (4 along M)
   constexpr int WTN = BN / WN;                      // wave tile width
   constexpr int NJ = WTN / 16;                      // 16-wide column sub-tiles per wave
+  constexpr int NT = (NJ + 3) / 4;                  // tail sub-tiles per wave: j = wm, wm + 4, ...
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 * STAGE
 
   const s4f_gemm_desc& d = args.d;
@@ -280,9 +297,47 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, c
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // folded row remainder (rows tiles_m * 256 .. M-1, at most 16): only the blocks of the last tile row carry it
+  const bool has_tail = CAN_TAIL && args.tail_rows > 0 && tm == args.tiles_m - 1;
+  f32x4 tacc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) tacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* tcur = nullptr;                       // waves 0 / 1: source of their 8-row tail DMA for the current k-step
+  int tkend = 0;
+  if constexpr (CAN_TAIL) {
+    if (has_tail && wave < 2) {
+      const int row = 8 * wave + (l >> 3);
+      const int chunk = (l & 7) ^ (row & 7);
+      const int gi = m0 + BM + row;
+      tkend = (gi < d.M && chunk * 8 < d.K) ? (d.K - chunk * 8 + BK - 1) / BK : 0;
+      tcur = reinterpret_cast<const char*>(d.A) + ((long)gi * d.lda + (long)kt_beg * BK + chunk * 8) * 2;
+    }
+  }
+  auto tail_issue = [&](int kt, char* stage) {
+    if constexpr (CAN_TAIL) {
+      if (has_tail && wave < 2) {                   // wave-uniform
+        glds16(kt < tkend ? tcur : g_zero_page, stage + T_OFF + wave * 1024);
+        tcur += BK * 2;
+      }
+    }
+  };
+  auto tail_mma = [&](const Frag<bf16_t> (&b)[NJ], const char* stage, int s) {
+    if constexpr (CAN_TAIL) {
+      if (has_tail) {                               // block-uniform
+        Frag<bf16_t> ta;
+        frag_row<TRMAP>(ta, stage + T_OFF, 0, s);
+        static_for<NJ>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if ((j & 3) == wm) tacc[j >> 2] = mma16(ta, b[j], tacc[j >> 2]);
+        });
+      }
+    }
+  };
+
   if (kt_beg < kt_end) {
     fa.issue(kt_beg, smem);
     fb.issue(kt_beg, smem + A_BYTES);
+    tail_issue(kt_beg, smem);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -295,7 +350,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, c
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      if constexpr (BKM) frag_k<BN>(b[j], Bs, wn * WTN + j * 16, s);
+      if constexpr (BKM) frag_k<BGEO>(b[j], Bs, wn * WTN + j * 16, s);
       else frag_row<TRMAP>(b[j], Bs, wn * WTN + j * 16, s);
     }
   };
@@ -344,13 +399,17 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, c
     char* Bs = As + A_BYTES;
     const bool more = kt + 1 < kt_end;
     char* An = smem + (cur ^ 1) * STAGE;
-    if (more) fa.issue(kt + 1, An);
+    if (more) {
+      fa.issue(kt + 1, An);
+      tail_issue(kt + 1, An);
+    }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       if (s == 1 && more) fb.issue(kt + 1, An + A_BYTES);
       Frag<bf16_t> a[4], b[NJ];
       load_frags(a, b, As, Bs, s);
       mma_all(a, b);
+      tail_mma(b, As, s);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -375,9 +434,19 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, c
     bf16_t* out_pre = reinterpret_cast<bf16_t*>(d.out_pre);
     const bf16_t* aux = reinterpret_cast<const bf16_t*>(d.aux);
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (CAN_TAIL ? 3 : 2); ++pass) {
+      if (pass == 2 && !has_tail) break;           // third pass: the folded tail rows (tile rows 0..15)
       __syncthreads();
-      if ((wm >> 1) == pass) {
+      if (pass == 2) {
+        static_for<NJ>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          if ((j & 3) == wm) {
+            const int col = wn * WTN + j * 16 + li;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(4 * g + r) * LDT + col] = tacc[j >> 2][r];
+          }
+        });
+      } else if ((wm >> 1) == pass) {
         const int rbase = (wm & 1) * 64;
         static_for<NJ>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
@@ -477,6 +546,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, c
         constexpr int i = decltype(ic)::value;
         epilogue_quad(d, acc[i][j], m0 + wm * 64 + i * 16 + 4 * g, n, bias, first_split);
       });
+      if (has_tail && (j & 3) == wm) epilogue_quad(d, tacc[j >> 2], m0 + BM + 4 * g, n, bias, first_split);
     }
   });
 }
@@ -509,6 +579,32 @@ __global__ __launch_bounds__(64 * NW) void gemm2_grouped_kernel(const GroupArgs 
   gemm2_body<BN, AMODE, BMODE, NW>(args, bx - start, blockIdx.z);
 }
 
+// tile grid of one problem; a row remainder of <= 16 rows is folded into the last tile row where the kernel can
+template <int BN, int AM, int NW>
+void set_tiles(GemmArgs& a) {
+  constexpr bool CAN_TAIL = (AM == S4F_OP_ROW) && !(NW == 8 && BN == 128);
+  const int rem = a.d.M % BM;
+  a.tiles_n = ceil_div(a.d.N, BN);
+  if (CAN_TAIL && rem > 0 && rem <= TAIL_MAX && a.d.M > BM) {
+    a.tiles_m = a.d.M / BM;
+    a.tail_rows = rem;
+  } else {
+    a.tiles_m = ceil_div(a.d.M, BM);
+    a.tail_rows = 0;
+  }
+}
+
+template <int BN, int AM, int BMo, int NW>
+size_t smem_bytes() {
+  constexpr bool BKM = (BMo == S4F_OP_K || BMo == S4F_OP_K_TAPSPLIT || BMo == S4F_OP_K_CONV);
+  constexpr bool CAN_TAIL = (AM == S4F_OP_ROW) && !(NW == 8 && BN == 128);
+  using FA = Feeder<AM, true, BM, NW>;
+  using FB = Feeder<BMo, false, (BKM && BN == 192) ? 256 : BN, NW, BN>;
+  size_t shm = 2 * (size_t)(FA::BYTES + FB::BYTES + (CAN_TAIL ? TAIL_BYTES : 0));
+  const size_t epi = (size_t)128 * (BN + 4) * 4;          // fp32 staging tile of the coalesced epilogue
+  return shm < epi ? epi : shm;
+}
+
 template <int BN, int AM, int BMo, int NW>
 int launch(const s4f_gemm_desc& d, hipStream_t st) {
   GemmArgs a;
@@ -518,13 +614,8 @@ int launch(const s4f_gemm_desc& d, hipStream_t st) {
   if (sk > a.nk) sk = a.nk;
   a.nk_per_split = ceil_div(a.nk, sk);
   sk = ceil_div(a.nk, a.nk_per_split);
-  a.tiles_m = ceil_div(d.M, BM);
-  a.tiles_n = ceil_div(d.N, BN);
-  using FA = Feeder<AM, true, BM, NW>;
-  using FB = Feeder<BMo, false, BN, NW>;
-  size_t shm = 2 * (size_t)(FA::BYTES + FB::BYTES);
-  const size_t epi = (size_t)128 * (BN + 4) * 4;          // fp32 staging tile of the coalesced epilogue
-  if (shm < epi) shm = epi;
+  set_tiles<BN, AM, NW>(a);
+  const size_t shm = smem_bytes<BN, AM, BMo, NW>();
   static bool attr_set = false;
   auto kern = gemm2_kernel<BN, AM, BMo, NW>;
   if (!attr_set) {
@@ -549,19 +640,14 @@ int launch_grouped(const s4f_gemm_desc* ds, int count, hipStream_t st) {
     if (sk > a.nk) sk = a.nk;
     a.nk_per_split = ceil_div(a.nk, sk);
     sk = ceil_div(a.nk, a.nk_per_split);
-    a.tiles_m = ceil_div(d.M, BM);
-    a.tiles_n = ceil_div(d.N, BN);
+    set_tiles<BN, AM, NW>(a);
     if (i < count) {
       total += a.tiles_m * a.tiles_n;
       if (sk > zmax) zmax = sk;
     }
     g.tile_end[i] = total;
   }
-  using FA = Feeder<AM, true, BM, NW>;
-  using FB = Feeder<BMo, false, BN, NW>;
-  size_t shm = 2 * (size_t)(FA::BYTES + FB::BYTES);
-  const size_t epi = (size_t)128 * (BN + 4) * 4;
-  if (shm < epi) shm = epi;
+  const size_t shm = smem_bytes<BN, AM, BMo, NW>();
   static bool attr_set = false;
   auto kern = gemm2_grouped_kernel<BN, AM, BMo, NW>;
   if (!attr_set) {
@@ -577,11 +663,14 @@ int dispatch(const s4f_gemm_desc& d, hipStream_t st) {
   const int am = d.a_mode, bm = d.b_mode;
   if (am == S4F_OP_ROW && bm == S4F_OP_ROW) return launch<BN, S4F_OP_ROW, S4F_OP_ROW, NW>(d, st);
   if (am == S4F_OP_ROW && bm == S4F_OP_K) return launch<BN, S4F_OP_ROW, S4F_OP_K, NW>(d, st);
+  if constexpr (BN == 192) return -100;            // the 192-column tile exists for the two token-GEMM forms only
+  else {
   if (am == S4F_OP_K && bm == S4F_OP_K) return launch<BN, S4F_OP_K, S4F_OP_K, NW>(d, st);
   if (am == S4F_OP_ROW_CONV && bm == S4F_OP_ROW) return launch<BN, S4F_OP_ROW_CONV, S4F_OP_ROW, NW>(d, st);
   if (am == S4F_OP_ROW_CONV && bm == S4F_OP_K_TAPSPLIT) return launch<BN, S4F_OP_ROW_CONV, S4F_OP_K_TAPSPLIT, NW>(d, st);
   if (am == S4F_OP_K && bm == S4F_OP_K_CONV) return launch<BN, S4F_OP_K, S4F_OP_K_CONV, NW>(d, st);
   return -100;
+  }
 }
 
 }  // namespace G2_NS
@@ -593,6 +682,7 @@ int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn) {
   if (d.dtype != S4F_BF16) return -100;
   if (d.b_mode == S4F_OP_K_CONV && (d.cC % 256) != 0 && bn == 256) return -100;   // tap must be uniform per N tile
   if (bn == 256) return d.tile_hint == 4 ? g2::dispatch<256, 16>(d, st) : g2::dispatch<256, 8>(d, st);
+  if (bn == 192) return d.tile_hint == 8 ? g2::dispatch<192, 16>(d, st) : g2::dispatch<192, 8>(d, st);
   return g2::dispatch<128, 8>(d, st);
 }
 

@@ -94,6 +94,8 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
             choice = (0, splitk)
         if choice is None:
             hints = [1, 2] + ([3, 4] if N % 256 == 0 and (b_mode != OP_K_CONV or conv[3] % 256 == 0) else [])
+            if N % 192 == 0 and a_mode == OP_ROW and b_mode in (OP_ROW, OP_K):
+                hints += [8, 9]                      # 256 x 192 tiles: N = 768 / 2304 -> 4 / 12 tile columns
             bk = 64
             nk = (K + bk - 1) // bk
             sks = sorted({max(1, min(nk, s_)) for s_ in ((splitk // 2, splitk, splitk * 2, splitk * 4) if atomic else (splitk,))})

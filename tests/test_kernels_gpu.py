@@ -489,7 +489,7 @@ def test_ema_sgd(K, code):
 
 
 # ------------------------------------------------------------------------------------------------ 256-row LDS-DMA kernel
-@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm2_dense_modes(K, hint):
     code = 1
     M, N, K_ = 1000, 768, 832
@@ -524,6 +524,50 @@ def test_gemm2_dense_modes(K, hint):
     K.gemm(dev(x21, code), dev(w21, code), M, 21, 256, 256, 256, code, out_f32=o21, ldo_f32=32, tile_hint=2)
     check(o21[:, :21], x21 @ w21.t(), code, 'gemm2 N=21')
     assert float(o21[:, 21:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('hint', [3, 4, 7, 8, 9])
+@pytest.mark.parametrize('M', [2 * 1025, 2 * 1025 + 6, 512 + 16, 256 + 1, 256 + 17, 255])
+def test_gemm2_folded_tail(K, hint, M):
+    """token GEMMs have M = B * 1025: a row remainder <= 16 is folded into the last tile row (hints 3/4/8/9), 17 is not;
+    every epilogue the transformer layer uses, NT and NN, incl. the 192-column tile with masked k-major columns"""
+    code = 1
+    N, K_ = 768, 192
+    x, w, b = q(rnd(M, K_, seed=1), code), q(rnd(N, K_, seed=2, scale=0.05), code), rnd(N, seed=3)
+    r = rnd(M, N, seed=4)
+    out = torch.empty(M, N, device='cuda')
+    out_t = torch.empty(M, N, device='cuda', dtype=tdt(code))
+    K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), resid=dev(r), ldr=N, out_f32=out, ldo_f32=N,
+           out_t=out_t, ldo_t=N, tile_hint=hint)
+    ref = r + O.linear(x, w, b)
+    check(out, ref, code, f'folded tail NT hint {hint} M {M}')
+    check(out_t, ref, code, f'folded tail NT (T out) hint {hint} M {M}')
+    # GELU epilogue with pre-activation derivative
+    out_pre = torch.empty_like(out_t)
+    K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), out_t=out_t, ldo_t=N, out_pre=out_pre, ldo_pre=N,
+           act=K.ACT_GELU, tile_hint=hint)
+    z = O.linear(x, w, b)
+    zr_ = z.clone().requires_grad_(True)
+    O.gelu(zr_).sum().backward()
+    check(out_pre, zr_.grad, code, f"folded tail gelu' hint {hint}"); check(out_t, O.gelu(z), code, f'folded tail gelu hint {hint}')
+    # NN with the GELU-backward epilogue: dz[M, K2] = (dy[M, N] w2[N, K2]) * gp, K2 = 3 * 192 (three 192-column tiles)
+    K2 = 576
+    dy, w2 = q(rnd(M, N, seed=5), code), q(rnd(N, K2, seed=6, scale=0.05), code)
+    gp = q(torch.rand(M, K2, generator=torch.Generator().manual_seed(7)) * 1.2 - 0.1, code)
+    dz = torch.empty(M, K2, device='cuda', dtype=tdt(code))
+    K.gemm(dev(dy, code), dev(w2, code), M, K2, N, N, K2, code, b_mode=K.OP_K, out_t=dz, ldo_t=K2, aux=dev(gp, code), ld_aux=K2,
+           act=K.ACT_GELU_BWD, tile_hint=hint if hint != 7 else 3)
+    check(dz, (dy @ w2) * gp, code, f'folded tail NN hint {hint} M {M}')
+    # narrow / ragged N (non-coalesced epilogue path): N = 200
+    w3 = q(rnd(200, K_, seed=8, scale=0.05), code)
+    o3 = torch.empty(M, 200, device='cuda')
+    K.gemm(dev(x, code), dev(w3, code), M, 200, K_, K_, K_, code, out_f32=o3, ldo_f32=200, tile_hint=hint)
+    check(o3, x @ w3.t(), code, f'folded tail ragged N hint {hint} M {M}')
+    # split-K with fp32 atomics (bias and residual enter once)
+    o4 = torch.zeros(M, N, device='cuda')
+    K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), resid=dev(r), ldr=N, out_f32=o4, ldo_f32=N,
+           atomic=True, splitk=3, tile_hint=hint)
+    check(o4, ref, code, f'folded tail split-K hint {hint} M {M}')
 
 
 @pytest.mark.parametrize('code', DTYPES)

@@ -53,7 +53,9 @@ if which in ('nt', 'nn'):
             if which == 'nn' and (N, Kd) == (2304, 768):
                 N, Kd = 768, 2304
             row = []
-            for hint in (1, 2, 3, 4):
+            for hint in (1, 2, 3, 4) + ((8, 9) if N % 192 == 0 else ()):
+                if hint in (3, 4) and N % 256:
+                    continue
                 us = f(M, N, Kd, hint)
                 row.append(f'h{hint} {us:7.1f}us {2.0 * M * N * Kd / us / 1e6:6.0f}TF')
             print(f'{which} M={M:6d} N={N:5d} K={Kd:5d} | ' + ' | '.join(row), flush=True)
