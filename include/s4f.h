@@ -98,6 +98,13 @@ int s4f_gemm_grouped(const s4f_gemm_desc* descs, int count, s4f_stream stream);
 int s4f_cast(const float* src, void* dst, int64_t n, int dtype, s4f_stream stream);
 /* s4f_cast_back: T -> fp32 */
 int s4f_cast_back(const void* src, float* dst, int64_t n, int dtype, s4f_stream stream);
+/* s4f_transpose_many: bf16 [R][T][C] -> [C][T][R] for n_items matrices of one source / one destination arena
+ * (R, C multiples of 64; offsets in elements, multiples of 4).  items_dev: device array of n_items x
+ * {src_off, dst_off, R, T, C, tile_start} int64, tile_start = running sum of T * (R / 64) * (C / 64); total_tiles = the
+ * final sum.  Produces the transposed weight shadows W^T (T = 1) and conv [ci][tap][co] (T = 9) with which the input
+ * gradients of F.linear (vit.py:99-127) and of the 3x3 convs (setr_up_head.py:57-68) run as row-major x row-major GEMMs. */
+int s4f_transpose_many(const void* src, void* dst, const int64_t* items_dev, int n_items, int total_tiles,
+                       s4f_stream stream);
 
 /* PatchEmbed im2col (embed.py:183-204): img fp32 [B,3,H,W] -> cols T, feature order (c, ky, kx), token order
  * row-major over the patch grid. H, W multiples of 16.  pad_cls = 0: cols [B*T, 768] (T = (H/16)*(W/16));

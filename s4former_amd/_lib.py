@@ -47,6 +47,7 @@ _SIGS = {
     's4f_gemm_grouped': [POINTER(GemmDesc), c_int, c_void_p],
     's4f_cast': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     's4f_cast_back': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    's4f_transpose_many': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     's4f_im2col_patch16': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     's4f_cls_pos': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     's4f_tokens_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

@@ -373,6 +373,45 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
 
 }  // namespace
 
+
+// ---------------------------------------------------------------- batched weight transposes
+// src [R][T][C] -> dst [C][T][R] (bf16) for a table of matrices: the transposed operand shadows that let every
+// input-gradient GEMM (dX = dY W, conv dgrad) run in the row-major x row-major form.  One 64 x 64 (r, c) tile of one
+// tap per block; items sit in device memory: {src_off, dst_off, R, T, C, tile_start} as int64.
+__global__ __launch_bounds__(256) void transpose_many_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                             const long* __restrict__ items, int n_items) {
+  __shared__ bf16_t tile[64][64 + 4];
+  const int b = blockIdx.x;
+  int it = 0;
+  for (int i = 1; i < n_items; ++i) it += (long)b >= items[6 * i + 5] ? 1 : 0;   // tile_start is ascending
+  const long* d = items + 6 * it;
+  const long soff = d[0], doff = d[1];
+  const int R = (int)d[2], T = (int)d[3], C = (int)d[4];
+  int local = b - (int)d[5];
+  const int tc = C / 64, tr = R / 64;
+  const int ct = local % tc; local /= tc;
+  const int rt = local % tr;
+  const int t = local / tr;
+  const int r0 = rt * 64, c0 = ct * 64;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 x 16 threads, 4 elements each per pass
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int r = ty + 16 * p;
+    const bf16x4 v = *reinterpret_cast<const bf16x4*>(src + soff + ((long)(r0 + r) * T + t) * C + c0 + 4 * tx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tile[r][4 * tx + e] = v[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int c = ty + 16 * p;
+    bf16x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = tile[4 * tx + e][c];
+    *reinterpret_cast<bf16x4*>(dst + doff + ((long)(c0 + c) * T + t) * R + r0 + 4 * tx) = v;
+  }
+}
+
 #define DT_CHECK(name) S4F_CHECK(dtype == S4F_F32 || dtype == S4F_BF16, name ": bad dtype %d", dtype)
 
 S4F_API int s4f_cast(const float* src, void* dst, int64_t n, int dtype, s4f_stream stream) {
@@ -394,6 +433,16 @@ S4F_API int s4f_cast_back(const void* src, float* dst, int64_t n, int dtype, s4f
   const int grid = grid_for(n, 256);
   if (dtype == S4F_BF16) hipLaunchKernelGGL(cast_back_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, (long)n);
   else hipLaunchKernelGGL(cast_back_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, (long)n);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_transpose_many(const void* src, void* dst, const int64_t* items_dev, int n_items, int total_tiles,
+                               s4f_stream stream) {
+  S4F_CHECK(src && dst && items_dev && n_items > 0 && total_tiles > 0, "s4f_transpose_many: bad args");
+  S4F_CHECK(((uintptr_t)src % 8) == 0 && ((uintptr_t)dst % 8) == 0, "s4f_transpose_many: arenas must be 8-B aligned");
+  hipLaunchKernelGGL(transpose_many_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     (bf16_t*)dst, (const long*)items_dev, n_items);
   S4F_LAUNCH_CHECK();
   return 0;
 }

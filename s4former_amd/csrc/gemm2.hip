@@ -240,6 +240,98 @@ __device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, i
   }
 }
 
+// One pass of the coalesced epilogue: 128 staged fp32 rows (tile, row stride BN + 4) -> global, 16 B per lane.
+// mrow0 = global row of staged row 0; rows >= M are skipped.
+template <int BN, int NW>
+__device__ __forceinline__ void epilogue_rows(const s4f_gemm_desc& d, const float* tile, const int mrow0, const int n0,
+                                              const bool first_split) {
+  constexpr int LDT = BN + 4;
+  constexpr int CPR = BN / 8;                    // 8-column chunks per row
+  constexpr int ITEMS = 128 * CPR / (64 * NW);   // chunk items per thread per pass
+  bf16_t* out_t = reinterpret_cast<bf16_t*>(d.out_t);
+  bf16_t* out_pre = reinterpret_cast<bf16_t*>(d.out_pre);
+  const bf16_t* aux = reinterpret_cast<const bf16_t*>(d.aux);
+  {
+    {
+      if (d.atomic) {
+        // split-K partial sums: fp32 atomics, each wave-instruction covers 64 consecutive columns (256 B) of one row
+        constexpr int AITEMS = 128 * BN / (64 * NW);
+#pragma unroll 4
+        for (int it = 0; it < AITEMS; ++it) {
+          const int idx = threadIdx.x + it * 64 * NW;
+          const int row = idx / BN, col = idx % BN;
+          const int m = mrow0 + row;
+          if (m >= d.M) continue;
+          float v = tile[row * LDT + col] * d.alpha;
+          if (first_split) {
+            if (d.bias) v += d.bias[n0 + col];
+            if (d.resid) v += d.resid[(long)m * d.ldr + n0 + col];
+          }
+          atomicAdd(d.out_f32 + (long)m * d.ldo_f32 + n0 + col, v);
+        }
+        return;
+      }
+#pragma unroll
+      for (int it = 0; it < ITEMS; ++it) {
+        const int idx = threadIdx.x + it * 64 * NW;
+        const int row = idx / CPR, cc = idx % CPR;
+        const int m = mrow0 + row;
+        if (m >= d.M) continue;
+        const int n = n0 + cc * 8;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cc * 8);
+        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cc * 8 + 4);
+        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+        if (d.bias && first_split) {
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + n), b1 = *reinterpret_cast<const f32x4*>(d.bias + n + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] = v[e] * d.alpha + b0[e]; v[4 + e] = v[4 + e] * d.alpha + b1[e]; }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= d.alpha;
+        }
+        if (d.pos) {
+          const float* pp = d.pos + (long)(m % d.pos_period) * d.N + n;
+          const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
+        }
+        if (d.act == S4F_ACT_GELU) {
+          bf16x8 pv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float gy, gd;
+            gelu_pair<false>(v[e], gy, gd);
+            v[e] = gy;
+            pv[e] = (bf16_t)gd;
+          }
+          if (out_pre) *reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n) = pv;
+        } else if (d.act == S4F_ACT_GELU_BWD) {
+          const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] *= (float)z[e];
+        }
+        if (d.resid && first_split) {
+          const float* rp = d.resid + (long)m * d.ldr + n;
+          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        }
+        if (d.out_f32) {
+          float* op = d.out_f32 + (long)m * d.ldo_f32 + n;
+          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        }
+        if (out_t) {
+          bf16x8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
+          *reinterpret_cast<bf16x8*>(out_t + (long)m * d.ldo_t + n) = ov;
+        }
+      }
+    }
+  }
+}
+
 template <int BN, int AMODE, int BMODE, int NW>
 __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, const int bz) {
   constexpr bool AK = (AMODE == S4F_OP_K);
@@ -428,11 +520,6 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, c
   if (wide) {
     constexpr int LDT = BN + 4;                    // fp32 row stride of the staging tile (pad: rows 4 apart -> other banks)
     float* tile = reinterpret_cast<float*>(smem);
-    constexpr int CPR = BN / 8;                    // 8-column chunks per row
-    constexpr int ITEMS = 128 * CPR / (64 * NW);   // chunk items per thread per pass
-    bf16_t* out_t = reinterpret_cast<bf16_t*>(d.out_t);
-    bf16_t* out_pre = reinterpret_cast<bf16_t*>(d.out_pre);
-    const bf16_t* aux = reinterpret_cast<const bf16_t*>(d.aux);
 #pragma unroll
     for (int pass = 0; pass < (CAN_TAIL ? 3 : 2); ++pass) {
       if (pass == 2 && !has_tail) break;           // third pass: the folded tail rows (tile rows 0..15)
@@ -459,81 +546,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, c
         });
       }
       __syncthreads();
-      if (d.atomic) {
-        // split-K partial sums: fp32 atomics, each wave-instruction covers 64 consecutive columns (256 B) of one row
-        constexpr int AITEMS = 128 * BN / (64 * NW);
-#pragma unroll 4
-        for (int it = 0; it < AITEMS; ++it) {
-          const int idx = threadIdx.x + it * 64 * NW;
-          const int row = idx / BN, col = idx % BN;
-          const int m = m0 + pass * 128 + row;
-          if (m >= d.M) continue;
-          float v = tile[row * LDT + col] * d.alpha;
-          if (first_split) {
-            if (d.bias) v += d.bias[n0 + col];
-            if (d.resid) v += d.resid[(long)m * d.ldr + n0 + col];
-          }
-          atomicAdd(d.out_f32 + (long)m * d.ldo_f32 + n0 + col, v);
-        }
-        continue;
-      }
-#pragma unroll
-      for (int it = 0; it < ITEMS; ++it) {
-        const int idx = threadIdx.x + it * 64 * NW;
-        const int row = idx / CPR, cc = idx % CPR;
-        const int m = m0 + pass * 128 + row;
-        if (m >= d.M) continue;
-        const int n = n0 + cc * 8;
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cc * 8);
-        const f32x4 t1 = *reinterpret_cast<const f32x4*>(tile + row * LDT + cc * 8 + 4);
-        float v[8] = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
-        if (d.bias && first_split) {
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(d.bias + n), b1 = *reinterpret_cast<const f32x4*>(d.bias + n + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] = v[e] * d.alpha + b0[e]; v[4 + e] = v[4 + e] * d.alpha + b1[e]; }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= d.alpha;
-        }
-        if (d.pos) {
-          const float* pp = d.pos + (long)(m % d.pos_period) * d.N + n;
-          const f32x4 p0 = *reinterpret_cast<const f32x4*>(pp), p1 = *reinterpret_cast<const f32x4*>(pp + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
-        }
-        if (d.act == S4F_ACT_GELU) {
-          bf16x8 pv;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float gy, gd;
-            gelu_pair<false>(v[e], gy, gd);
-            v[e] = gy;
-            pv[e] = (bf16_t)gd;
-          }
-          if (out_pre) *reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n) = pv;
-        } else if (d.act == S4F_ACT_GELU_BWD) {
-          const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= (float)z[e];
-        }
-        if (d.resid && first_split) {
-          const float* rp = d.resid + (long)m * d.ldr + n;
-          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
-        }
-        if (d.out_f32) {
-          float* op = d.out_f32 + (long)m * d.ldo_f32 + n;
-          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<f32x4*>(op + 4) = f32x4{v[4], v[5], v[6], v[7]};
-        }
-        if (out_t) {
-          bf16x8 ov;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x8*>(out_t + (long)m * d.ldo_t + n) = ov;
-        }
-      }
+      epilogue_rows<BN, NW>(d, tile, m0 + pass * 128, n0, first_split);
     }
     return;
   }

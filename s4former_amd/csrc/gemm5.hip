@@ -1,0 +1,417 @@
+// tile_hint 10: 256 x 256 x 64 bf16 GEMM with EIGHT waves in a ping-pong schedule (guide §5 "The 256^2 8-phase template",
+// MI355X_MICROARCH "Two waves per SIMD"): waves 0-3 (wr = 0) own the upper 128 rows of the tile, waves 4-7 (wr = 1) the
+// lower 128; wave w and w + 4 share a SIMD.  A K-tile is four phases; in each phase one wave of a SIMD issues 16 MFMAs
+// (one 64 x 32 quadrant of its 128 x 64 output x K = 64) at s_setprio 1 while its partner - one s_barrier behind - reads
+// the fragments of its next quadrant from LDS and issues the LDS-DMA of one quarter of a later K-tile:
+//
+//   wr = 0:  L1 |b| M1 |b| L2 |b| M2 |b| L3 ...          L = ds_read fragments + 2 global_load_lds + counted vmcnt
+//   wr = 1:     |b| L1 |b| M1 |b| L2 |b| M2 ...          M = s_waitcnt lgkmcnt(0), 16 x v_mfma_f32_16x16x32_bf16
+//
+// Two 64 KiB LDS buffers (K-tile t lives in buffer t & 1).  Each operand tile is cut into the part read in one phase:
+//   AL rows 0-63 of each 128-row half (read in phase 1)      BL columns 0-31 of each 64-column strip (phase 1)
+//   BH columns 32-63 of each strip  (phase 2)                AH rows 64-127 of each half (phase 3);   phase 4 reads nothing
+// (quadrant order (AL,BL) (AL,BH) (AH,BH) (AH,BL): A fragments live two phases, both B fragment sets the whole K-tile).
+// A part of K-tile t + 2 is re-staged over the same part of K-tile t two or three phases after its last read:
+//   phase 1 issues BH(t+1), phase 2 AH(t+1), phase 3 AL(t+2), phase 4 BL(t+2)   -> every DMA has >= 5 phases to land;
+// each part is 2 DMA instructions per wave, the wait in phase p certifies the part read in phase p + 1 and leaves the
+// four younger parts in flight: s_waitcnt vmcnt(8) in every phase (9 with the folded tail: AL carries one more DMA).
+// RAW: a wave's counted wait precedes a barrier that every reader passes before the read (one barrier more for the
+// staggered group: the wait sits a whole phase ahead).  WAR: a part's last ds_reads are retired by lgkmcnt(0) at least
+// two barriers before the first DMA that overwrites it is issued.
+//
+// Operand modes: A row-major or implicit-conv gather (S4F_OP_ROW, S4F_OP_ROW_CONV), B row-major; every epilogue of the
+// family (shared code of gemm2.hip).  A row remainder of <= 16 rows is folded into the last tile row like in gemm2.hip.
+#define G2_NS g5
+#define G2_VARIANT_ONLY 1
+#include "gemm2.hip"
+
+namespace g5 {
+
+constexpr int P_AL = 0, P_AH = 1, P_BL = 0, P_BH = 1;
+constexpr int G5_A = 256 * 128, G5_B = 256 * 128;   // bytes of the A / B image of one K-tile
+constexpr int G5_TAILB = 8 * 1024;                    // tail region per buffer: one DMA per wave (2 KiB used)
+constexpr int G5_BUF = G5_A + G5_B;                   // 64 KiB
+constexpr int G5_TAIL0 = 2 * G5_BUF;                  // tail images behind the two buffers
+
+constexpr int G5_OOB = (int)0x80000000;               // buffer offset beyond num_records: the load returns zeros
+
+__device__ __forceinline__ void bufl16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
+
+// Row-major image feeder for the part-wise schedule: 4 DMA slots per thread, slots {0, 1} = low part, {2, 3} = high part.
+// Sources are addressed through a buffer resource: per slot ONE 32-bit lane offset that is constant over the K loop
+// (dense) or over a filter tap (conv gather); the k position is the scalar offset.  Rows outside the problem, conv
+// padding and K-tiles past the block's k range get an out-of-range offset: the hardware returns zeros (no zero page,
+// no memory traffic).
+template <int MODE, bool IS_A>
+struct PFeeder {
+  __amdgpu_buffer_rsrc_t rsrc;
+  long ld;
+  int cH, cW, cC, csign, kt_end;
+  int voff[4];
+  int pyx[4], pb[4];            // conv: (y << 16 | x), image index of the slot's pixel
+  int chunk;                    // source 16-B chunk of this lane inside the 128-B k-row (swizzle applied)
+  int soff[2];                  // conv: scalar byte offset of the part's current tap is folded into voff; this is the k base
+  int wave;
+
+  // 8-row block of slot u: A parts are rows {0-63, 128-191} / {64-127, 192-255}; B parts are the low / high 32 columns
+  // of each 64-column strip
+  __device__ __forceinline__ int block_of(int u) const {
+    const int part = u >> 1, i = u & 1;
+    if constexpr (IS_A) return wave + 16 * i + 8 * part;
+    const int e = wave + 8 * i;
+    return 8 * (e >> 2) + (e & 3) + 4 * part;
+  }
+
+  template <int PART>
+  __device__ __forceinline__ void seek(int kt) {
+    if constexpr (MODE == S4F_OP_ROW_CONV) {
+      const int k0 = kt * BK;
+      const int tap = k0 / cC;
+      const int ty = tap / 3, tx = tap - 3 * ty;
+      soff[PART] = (tap * cC) * 2;                   // k bytes already consumed by earlier taps
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int u = 2 * PART + i;
+        const int yy = (pyx[u] >> 16) + csign * (ty - 1), xx = (pyx[u] & 0xffff) + csign * (tx - 1);
+        const bool ok = pb[u] >= 0 && yy >= 0 && yy < cH && xx >= 0 && xx < cW;
+        voff[u] = ok ? (int)(((((long)pb[u] * cH + yy) * cW + xx) * ld + chunk * 8) * 2) : G5_OOB;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void init(const s4f_gemm_desc& d, int blk0, int kt0, int kt_end_) {
+    wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const void* basep = IS_A ? d.A : d.B;
+    ld = IS_A ? d.lda : d.ldb;
+    const int lim = IS_A ? d.M : d.N;
+    cH = d.cH; cW = d.cW; cC = d.cC; csign = d.csign; kt_end = kt_end_;
+    long bytes;
+    if constexpr (MODE == S4F_OP_ROW) bytes = ((long)(lim - 1) * ld + d.K) * 2;
+    else bytes = (long)d.cB * d.cH * d.cW * ld * 2;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(basep), 0, (int)bytes, 0x00020000);
+    chunk = (lane & 7) ^ (lane >> 3);            // row & 7 == lane >> 3 for every block
+    soff[0] = soff[1] = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int gi = blk0 + 8 * block_of(u) + (lane >> 3);
+      if constexpr (MODE == S4F_OP_ROW) {
+        voff[u] = gi < lim ? (int)(((long)gi * ld + chunk * 8) * 2) : G5_OOB;
+      } else {
+        const int x = gi % cW;
+        const int tt = gi / cW;
+        pyx[u] = ((tt % cH) << 16) | x;
+        pb[u] = gi < lim ? tt / cH : -1;
+      }
+    }
+    seek<0>(kt0);
+    seek<1>(kt0);
+  }
+
+  // two DMA instructions: part PART of K-tile kt into the image at img
+  template <int PART>
+  __device__ __forceinline__ void issue(int kt, char* img) {
+    if constexpr (MODE == S4F_OP_ROW_CONV) {
+      if ((kt * BK) % cC == 0 && kt < kt_end) seek<PART>(kt);       // wave-uniform: tap changed
+    }
+    const bool live = kt < kt_end;                   // scalar
+    const int so = kt * (BK * 2) - (MODE == S4F_OP_ROW_CONV ? soff[PART] : 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = 2 * PART + i;
+      bufl16(rsrc, live ? voff[u] : G5_OOB, so, img + block_of(u) * 1024);
+    }
+  }
+};
+
+template <int AMODE, bool TAIL, int DBG = 0>
+__device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, const int tn, const int bz, char* smem) {
+  const s4f_gemm_desc& d = args.d;
+  const int m0 = tm * BM, n0 = tn * 256;
+  const int kt_beg = bz * args.nk_per_split;
+  int kt_end = kt_beg + args.nk_per_split;
+  if (kt_end > args.nk) kt_end = args.nk;
+
+  const int wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l = threadIdx.x & 63, g = l >> 4, li = l & 15;
+
+  PFeeder<AMODE, true> fa;
+  PFeeder<S4F_OP_ROW, false> fb;
+  fa.init(d, m0, kt_beg, kt_end);
+  fb.init(d, n0, kt_beg, kt_end);
+
+  // folded tail: every wave issues ONE extra DMA with the AL part (waves 0 / 1 fetch the 16 tail rows, the others an
+  // out-of-range offset = zeros into a dummy slot) so that the vmcnt bookkeeping is the same in all waves
+  int tvoff = G5_OOB;
+  if constexpr (TAIL) {
+    if (wave < 2) {
+      const int row = 8 * wave + (l >> 3);
+      const int chunk = (l & 7) ^ (l >> 3);
+      const int gi = m0 + BM + row;
+      if (gi < d.M) tvoff = (int)(((long)gi * d.lda + chunk * 8) * 2);
+    }
+  }
+  auto tail_issue = [&](int kt, int buf) {
+    if constexpr (TAIL) bufl16(fa.rsrc, kt < kt_end ? tvoff : G5_OOB, kt * (BK * 2), smem + G5_TAIL0 + buf * G5_TAILB + wave * 1024);
+  };
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 tacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+
+  // ---- prologue: K-tile 0 complete, AL / BL of K-tile 1
+  {
+    char* b0 = smem;
+    char* b1 = smem + G5_BUF;
+    fa.template issue<P_AL>(kt_beg, b0);
+    tail_issue(kt_beg, 0);
+    fb.template issue<P_BL>(kt_beg, b0 + G5_A);
+    fb.template issue<P_BH>(kt_beg, b0 + G5_A);
+    fa.template issue<P_AH>(kt_beg, b0);
+    fa.template issue<P_AL>(kt_beg + 1, b1);
+    tail_issue(kt_beg + 1, 1);
+    fb.template issue<P_BL>(kt_beg + 1, b1 + G5_A);
+  }
+  if constexpr (TAIL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();         // stagger: the lower half runs one barrier behind
+
+  Frag<bf16_t> a[4][2], bl[2][2], bh[2][2], ta[2];
+
+  auto wait_parts = [&]() {
+    if constexpr (TAIL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  };
+  auto read_a = [&](const char* As, int half) {       // 64 rows x 64 k of this wave's 128-row half
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) frag_row<false>(a[i][s], As, wr * 128 + half * 64 + i * 16, s);
+  };
+  auto read_b = [&](Frag<bf16_t> (&b)[2][2], const char* Bs, int half) {   // 32 columns x 64 k of this wave's strip
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) frag_row<false>(b[j][s], Bs, wc * 64 + half * 32 + j * 16, s);
+  };
+  auto mma_quad = [&](auto ahc, auto bhc, const Frag<bf16_t> (&b)[2][2]) {
+    constexpr int AH = decltype(ahc)::value, BH = decltype(bhc)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[AH * 4 + i][BH * 2 + j] = mma16(a[i][s], b[j][s], acc[AH * 4 + i][BH * 2 + j]);
+  };
+  auto seg_begin = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+  };
+  auto seg_end = [&]() {
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  auto ktile = [&](auto bufc, int kt) {
+    constexpr int BUF = decltype(bufc)::value;
+    char* cur = smem + BUF * G5_BUF;
+    char* nxt = smem + (BUF ^ 1) * G5_BUF;
+    const char* As = cur;
+    const char* Bs = cur + G5_A;
+    // phase 1: quadrant (AL, BL)
+    read_a(As, 0);
+    read_b(bl, Bs, 0);
+    if constexpr (TAIL) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) frag_row<false>(ta[s], smem + G5_TAIL0 + BUF * G5_TAILB, 0, s);
+    }
+    fb.template issue<P_BH>(kt + 1, nxt + G5_A);
+    wait_parts();
+    seg_begin();
+    mma_quad(I0{}, I0{}, bl);
+    if constexpr (TAIL) {
+      if (wr == 0) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) tacc[j] = mma16(ta[s], bl[j][s], tacc[j]);
+      }
+    }
+    seg_end();
+    // phase 2: quadrant (AL, BH)
+    read_b(bh, Bs, 1);
+    fa.template issue<P_AH>(kt + 1, nxt);
+    wait_parts();
+    seg_begin();
+    mma_quad(I0{}, I1{}, bh);
+    if constexpr (TAIL) {
+      if (wr == 1) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) tacc[j] = mma16(ta[s], bh[j][s], tacc[j]);
+      }
+    }
+    seg_end();
+    // phase 3: quadrant (AH, BH)
+    read_a(As, 1);
+    fa.template issue<P_AL>(kt + 2, cur);
+    tail_issue(kt + 2, BUF);
+    wait_parts();
+    seg_begin();
+    mma_quad(I1{}, I1{}, bh);
+    seg_end();
+    // phase 4: quadrant (AH, BL)
+    fb.template issue<P_BL>(kt + 2, cur + G5_A);
+    wait_parts();
+    seg_begin();
+    mma_quad(I1{}, I0{}, bl);
+    seg_end();
+  };
+
+  if (DBG != 2) {
+  for (int kt = kt_beg; kt < kt_end; kt += 2) {
+    ktile(I0{}, kt);
+    if (kt + 1 < kt_end) ktile(I1{}, kt + 1);
+  }
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();         // undo the stagger
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zero-page DMAs of the drained pipeline still target LDS
+  __syncthreads();
+
+  if (DBG == 1) {                                     // timing probe: no epilogue (accumulators kept live)
+    f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) sacc += acc[i][j];
+    if (sacc[0] + sacc[1] + sacc[2] + sacc[3] == 123.456f) reinterpret_cast<bf16_t*>(d.out_t)[0] = (bf16_t)1.f;
+    return;
+  }
+  // ------------------------------------------------------------------ epilogue (same contract as gemm2.hip)
+  const bool first_split = (bz == 0);
+  const bool wide = (d.N % 8 == 0) && (n0 + 256 <= d.N) && (!d.atomic || (d.act == S4F_ACT_NONE && !d.out_t && !d.pos)) &&
+                    (!d.out_t || d.ldo_t % 8 == 0) && (!d.out_pre || d.ldo_pre % 8 == 0) && (!d.aux || d.ld_aux % 8 == 0) &&
+                    (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % 4 == 0);
+  if (wide) {
+    constexpr int LDT = 256 + 4;
+    float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int pass = 0; pass < (TAIL ? 3 : 2); ++pass) {
+      __syncthreads();
+      if (pass == 2) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tile[(4 * g + r) * LDT + wc * 64 + wr * 32 + j * 16 + li] = tacc[j][r];
+      } else if (wr == pass) {
+        static_for<8>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          static_for<4>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tile[(i * 16 + 4 * g + r) * LDT + wc * 64 + j * 16 + li] = acc[i][j][r];
+          });
+        });
+      }
+      __syncthreads();
+      epilogue_rows<256, 8>(d, tile, m0 + pass * 128, n0, first_split);
+    }
+    return;
+  }
+  static_for<4>([&](auto jc) {
+    constexpr int j = decltype(jc)::value;
+    const int n = n0 + wc * 64 + j * 16 + li;
+    if (n < d.N) {
+      const float bias = (d.bias && first_split) ? d.bias[n] : 0.f;
+      static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        epilogue_quad(d, acc[i][j], m0 + wr * 128 + i * 16 + 4 * g, n, bias, first_split);
+      });
+      if constexpr (TAIL) {
+        if ((j >> 1) == wr) epilogue_quad(d, tacc[j & 1], m0 + BM + 4 * g, n, bias, first_split);
+      }
+    }
+  });
+}
+
+template <int AMODE, int DBG>
+__global__ __launch_bounds__(512) void gemm5_kernel(const GemmArgs args) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // XCD-aware bijective remap + grouped tile order (as gemm2.hip)
+  const int nt = args.tiles_m * args.tiles_n;
+  int L = blockIdx.x;
+  {
+    const int xcd = L & 7, q8 = nt >> 3, r8 = nt & 7;
+    const int basei = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    L = basei + (L >> 3);
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * args.tiles_n;
+  const int grp = L / per_group, r = L - grp * per_group;
+  const int rows_here = min(GM, args.tiles_m - grp * GM);
+  const int tm = grp * GM + r % rows_here;
+  const int tn = r / rows_here;
+  if (AMODE == S4F_OP_ROW && args.tail_rows > 0 && tm == args.tiles_m - 1) g5_body<AMODE, true, DBG>(args, tm, tn, blockIdx.z, smem);
+  else g5_body<AMODE, false, DBG>(args, tm, tn, blockIdx.z, smem);
+}
+
+template <int AMODE, int DBG = 0>
+int launch5(const s4f_gemm_desc& d, hipStream_t st) {
+  GemmArgs a;
+  a.d = d;
+  a.nk = ceil_div(d.K, BK);
+  int sk = d.splitk < 1 ? 1 : d.splitk;
+  if (sk > a.nk) sk = a.nk;
+  a.nk_per_split = ceil_div(a.nk, sk);
+  sk = ceil_div(a.nk, a.nk_per_split);
+  a.tiles_n = ceil_div(d.N, 256);
+  const int rem = d.M % BM;
+  if (AMODE == S4F_OP_ROW && rem > 0 && rem <= TAIL_MAX && d.M > BM) {
+    a.tiles_m = d.M / BM;
+    a.tail_rows = rem;
+  } else {
+    a.tiles_m = ceil_div(d.M, BM);
+    a.tail_rows = 0;
+  }
+  // buffer addressing: 31-bit byte offsets; whole K-tiles only (no k edge inside a 16-B chunk row)
+  const long a_bytes = (AMODE == S4F_OP_ROW) ? ((long)(d.M - 1) * d.lda + d.K) * 2 : (long)d.cB * d.cH * d.cW * d.lda * 2;
+  const long b_bytes = ((long)(d.N - 1) * d.ldb + d.K) * 2;
+  if (d.K % BK != 0 || a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return -100;
+  const size_t shm = 2 * (size_t)G5_BUF + 2 * (size_t)G5_TAILB;     // 144 KiB (epilogue staging tile: 130 KiB)
+  static bool attr_set = false;
+  auto kern = gemm5_kernel<AMODE, DBG>;
+  if (!attr_set) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, 1, sk), dim3(512), shm, st, a);
+  return 0;
+}
+
+}  // namespace g5
+
+int s4f_gemm5_try(const s4f_gemm_desc& d, hipStream_t st) {
+  if (d.dtype != S4F_BF16 || d.b_mode != S4F_OP_ROW) return -100;
+#ifdef G5_PROBES
+  if (d.a_mode == S4F_OP_ROW && d.tile_hint == 11) return g5::launch5<S4F_OP_ROW, 1>(d, st);
+  if (d.a_mode == S4F_OP_ROW && d.tile_hint == 12) return g5::launch5<S4F_OP_ROW, 2>(d, st);
+#endif
+  if (d.a_mode == S4F_OP_ROW) return g5::launch5<S4F_OP_ROW>(d, st);
+  if (d.a_mode == S4F_OP_ROW_CONV) return g5::launch5<S4F_OP_ROW_CONV>(d, st);
+  return -100;
+}

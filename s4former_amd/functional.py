@@ -163,6 +163,15 @@ def _handed_colsum(g):
     return None
 
 
+def _dgrad(dy, w, M, N, Kd, store, code, **epi):
+    """dx[M, N] = dy[M, Kd] W[Kd, N]  (W = F.linear weight [out = Kd, in = N]).  bf16: row-major x row-major against the
+    transposed shadow W^T [N][Kd] (the fastest kernel forms, incl. the 8-wave ping-pong one); fp32: W read k-major."""
+    if code == BF16:
+        K.gemm(dy, store.shadow_T(w), M, N, Kd, Kd, Kd, code, **epi)
+    else:
+        K.gemm(dy, store.shadow(w), M, N, Kd, Kd, N, code, b_mode=K.OP_K, **epi)
+
+
 def _wgrad(dy, x, M, N, rows, ldm, ldn, out, code):
     """out[M,N] += dy[rows,M]^T x[rows,N]   (fp32 atomic accumulate into the gradient arena)"""
     K.gemm(dy, x, M, N, rows, ldm, ldn, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=out, ldo_f32=N, atomic=True,
@@ -270,13 +279,12 @@ class LayerFn(Function):
         else:
             store.grad_phys(bf2).add_(g2cs)
         dz = torch.empty(M, F_, device=dev, dtype=T)
-        K.gemm(g2t, store.shadow(w2), M, F_, E, E, F_, code, b_mode=K.OP_K, out_t=dz, ldo_t=F_, aux=sv['z'], ld_aux=F_,
-               act=K.ACT_GELU_BWD)
+        _dgrad(g2t, w2, M, F_, E, store, code, out_t=dz, ldo_t=F_, aux=sv['z'], ld_aux=F_, act=K.ACT_GELU_BWD)
         sv['z'] = sv['a'] = None
         with on_side(dev, dz):
             K.colsum(dz, F_, M, F_, store.grad_phys(bf1), code)
         dxn2 = torch.empty(M, E, device=dev, dtype=T)
-        K.gemm(dz, store.shadow(w1), M, E, F_, F_, E, code, b_mode=K.OP_K, out_t=dxn2, ldo_t=E)
+        _dgrad(dz, w1, M, E, F_, store, code, out_t=dxn2, ldo_t=E)
         g1 = torch.empty(Bn, N, E, device=dev)
         g1t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
         # the column sums of g1 (= the proj bias gradient) come out of the same pass
@@ -286,7 +294,7 @@ class LayerFn(Function):
             g1t = g1
         # ---- attention
         dctx = torch.empty(M, E, device=dev, dtype=T)
-        K.gemm(g1t, store.shadow(wo), M, E, E, E, E, code, b_mode=K.OP_K, out_t=dctx, ldo_t=E)
+        _dgrad(g1t, wo, M, E, E, store, code, out_t=dctx, ldo_t=E)
         dqkv = torch.empty(M, 3 * E, device=dev, dtype=T)
         delta = torch.empty(Bn, H, N, device=dev)
         K.attention_bwd(sv['qkv'], sv['ctxv'], dctx, sv['lse'], delta, dqkv, Bn, N, H, code, bias_u=sv['bias_u'],
@@ -298,7 +306,7 @@ class LayerFn(Function):
                              (g1t, ctxv, E, E, M, store.grad_phys(wo))], code)
             K.colsum(dqkv, 3 * E, M, 3 * E, store.grad_phys(bqkv), code)
         dxn = torch.empty(M, E, device=dev, dtype=T)
-        K.gemm(dqkv, store.shadow(wqkv), M, E, 3 * E, 3 * E, E, code, b_mode=K.OP_K, out_t=dxn, ldo_t=E)
+        _dgrad(dqkv, wqkv, M, E, 3 * E, store, code, out_t=dxn, ldo_t=E)
         del dqkv, dz
         g0 = torch.empty(Bn, N, E, device=dev)
         g0t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
@@ -426,15 +434,20 @@ def head_backward(dlo, dlo_t, sv, hp, store):
                    splitk=_splitk(_tiles(Cc, 9 * cin_k), _nk(Mk, code), target=768), conv=(Bn, h, w, cin_k, 1))
         st['inp'] = None
         dcur = torch.empty(Mk, cin_k, device=dev, dtype=T)
+        # input gradient = the same implicit GEMM with mirrored taps (csign -1).  bf16: against the [ci][tap][co] shadow
+        # (row-major B, the forward kernel forms); fp32: the stored [co][tap][ci] weights read tap-split k-major.
+        if code == BF16:
+            wB, bm, ldb = store.shadow_T(cv['w']), K.OP_ROW, 9 * Cc
+        else:
+            wB, bm, ldb = store.shadow(cv['w']), K.OP_K_TAPSPLIT, 9 * cin_k
         if code == BF16 and _tiles256(Mk, cin_k) < 128:
             df = torch.zeros(Mk, cin_k, device=dev)
-            K.gemm(dy, store.shadow(cv['w']), Mk, cin_k, 9 * Cc, Cc, 9 * cin_k, code, a_mode=K.OP_ROW_CONV,
-                   b_mode=K.OP_K_TAPSPLIT, out_f32=df, ldo_f32=cin_k, atomic=True,
-                   splitk=max(2, min(8, 256 // _tiles256(Mk, cin_k))), conv=(Bn, h, w, Cc, -1))
+            K.gemm(dy, wB, Mk, cin_k, 9 * Cc, Cc, ldb, code, a_mode=K.OP_ROW_CONV, b_mode=bm, out_f32=df, ldo_f32=cin_k,
+                   atomic=True, splitk=max(2, min(8, 256 // _tiles256(Mk, cin_k))), conv=(Bn, h, w, Cc, -1))
             K.cast(df, dcur, code)
         else:
-            K.gemm(dy, store.shadow(cv['w']), Mk, cin_k, 9 * Cc, Cc, 9 * cin_k, code, a_mode=K.OP_ROW_CONV,
-                   b_mode=K.OP_K_TAPSPLIT, out_t=dcur, ldo_t=cin_k, conv=(Bn, h, w, Cc, -1))
+            K.gemm(dy, wB, Mk, cin_k, 9 * Cc, Cc, ldb, code, a_mode=K.OP_ROW_CONV, b_mode=bm, out_t=dcur, ldo_t=cin_k,
+                   conv=(Bn, h, w, Cc, -1))
         del dy
     gh, gw = hp['grid']
     dtok = torch.zeros(Bn, ntok, E, device=dev)

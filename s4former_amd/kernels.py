@@ -11,7 +11,7 @@ from . import _lib as L
 from ._lib import (ACT_GELU, ACT_GELU_BWD, ACT_NONE, BF16, F32, OP_K, OP_K_CONV, OP_K_TAPSPLIT, OP_ROW,
                    OP_ROW_CONV, S4FError, call, p, stream)
 
-__all__ = ['gemm', 'wgrad_grouped', 'cast', 'cast_back', 'im2col_patch16', 'cls_pos', 'tokens_bwd', 'colsum', 'layernorm_fwd',
+__all__ = ['gemm', 'wgrad_grouped', 'transpose_many', 'cast', 'cast_back', 'im2col_patch16', 'cls_pos', 'tokens_bwd', 'colsum', 'layernorm_fwd',
            'layernorm_bwd', 'add_f32', 'attention_fwd', 'attention_bwd', 'bn_stats', 'bn_finalize',
            'bn_relu_up_fwd', 'bn_relu_up_bwd', 'bn_bwd_apply', 'bn_param_grads', 'upce_fwd', 'upce_bwd',
            'up_pseudo_label', 'up_logits_nchw', 'ce_fwd', 'ce_bwd', 'ema', 'sgd_momentum']
@@ -96,6 +96,8 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
             hints = [1, 2] + ([3, 4] if N % 256 == 0 and (b_mode != OP_K_CONV or conv[3] % 256 == 0) else [])
             if N % 192 == 0 and a_mode == OP_ROW and b_mode in (OP_ROW, OP_K):
                 hints += [8, 9]                      # 256 x 192 tiles: N = 768 / 2304 -> 4 / 12 tile columns
+            if N % 256 == 0 and K % 64 == 0 and b_mode == OP_ROW and a_mode in (OP_ROW, OP_ROW_CONV) and splitk == 1:
+                hints += [10]                        # 8-wave ping-pong kernel (wins from K ~ 1536 up)
             bk = 64
             nk = (K + bk - 1) // bk
             sks = sorted({max(1, min(nk, s_)) for s_ in ((splitk // 2, splitk, splitk * 2, splitk * 4) if atomic else (splitk,))})
@@ -227,6 +229,22 @@ def cast_back(src, dst, dtype):
     _chk_f32(dst, 'cast_back dst'); _chk_dtype(src, dtype, 'cast_back src')
     _need(src, dst.numel(), 'cast_back src'); _need(dst, src.numel(), 'cast_back dst')
     call('s4f_cast_back', p(src), p(dst), src.numel(), dtype, stream())
+
+
+def transpose_many(src, dst, items_dev, items_host):
+    """items_host: list of (src_off, dst_off, R, T, C, tile_start); items_dev the same as an int64 device tensor"""
+    if src.dtype != torch.bfloat16 or dst.dtype != torch.bfloat16:
+        raise S4FError('transpose_many: bf16 arenas expected')
+    if items_dev.dtype != torch.int64 or items_dev.numel() != 6 * len(items_host):
+        raise S4FError('transpose_many: bad item table')
+    total = 0
+    for (so, do, R, T, C, ts) in items_host:
+        if R % 64 or C % 64 or so % 4 or do % 4 or ts != total:
+            raise S4FError(f'transpose_many: bad item {(so, do, R, T, C, ts)}')
+        if so + R * T * C > src.numel() or do + R * T * C > dst.numel():
+            raise S4FError('transpose_many: item outside its arena')
+        total += T * (R // 64) * (C // 64)
+    call('s4f_transpose_many', p(src), p(dst), p(items_dev), len(items_host), total, stream())
 
 
 def im2col_patch16(img, cols, dtype, pad_cls=False):

@@ -70,6 +70,8 @@ class S4FSGD(torch.optim.Optimizer):
                     K.sgd_momentum(store.flat[e.off:e.off + n], store.grad[e.off:e.off + n], store.mom[e.off:e.off + n], pt,
                                    n, g['lr'], g['momentum'], grad_scale, first, store.dtype)
         store.first_sgd_step = False
+        if store.flat_t is not None and store._T_items:
+            store.sync_T(eager=True)      # transposed operand shadows follow the bf16 shadow the SGD kernels just wrote
         return loss
 
     def zero_grad(self, set_to_none=False):

@@ -23,7 +23,8 @@ def _is_conv3x3(t):
 
 
 class _Entry:
-    __slots__ = ('module', 'attr', 'is_param', 'name', 'group', 'shape', 'numel', 'off', 'cl', 'v_phys', 'v_grad', 'v_shadow')
+    __slots__ = ('module', 'attr', 'is_param', 'name', 'group', 'shape', 'numel', 'off', 'cl', 'v_phys', 'v_grad', 'v_shadow',
+                 'v_T')
 
 
 class ParamStore:
@@ -121,6 +122,11 @@ class ParamStore:
             src = self.flat_t if self.flat_t is not None else flat
             e.v_shadow = src[e.off:e.off + e.numel]
         self.generation = getattr(self, 'generation', 0) + 1
+        self.flat_T = None           # transposed bf16 shadows (same offsets as flat_t), allocated on first use
+        self._T_items = {}           # entry offset -> (R, T, C)
+        self._T_table = None         # (device int64 table, host item list)
+        self._T_fresh = False
+        self._T_event = None
         self._shadow_dirty = True
         self._versions = None
         self.first_sgd_step = True
@@ -182,6 +188,63 @@ class ParamStore:
 
     def mark_dirty(self):
         self._shadow_dirty = True
+        self._T_fresh = False
+
+    # ------------------------------------------------------------------ transposed operand shadows (bf16 mode)
+    def _T_rebuild_table(self):
+        items, total = [], 0
+        for off in sorted(self._T_items):
+            R, T, C = self._T_items[off]
+            items.append((off, off, R, T, C, total))
+            total += T * (R // 64) * (C // 64)
+        dev = torch.tensor([v for it in items for v in it], dtype=torch.int64, device=self.flat.device)
+        self._T_table = (dev, items)
+
+    def sync_T(self, eager=False):
+        """(re)make every registered transposed shadow from the bf16 shadow arena in ONE launch on the current stream.
+        eager=True: called on the optimiser's stream right after the SGD kernels; every stream of the next step forks
+        from that stream, so no event is needed.  Otherwise users wait for the recorded event."""
+        if not self._T_items:
+            self._T_fresh = True
+            return
+        if self._T_table is None:
+            self._T_rebuild_table()
+        K.transpose_many(self.flat_t, self.flat_T, self._T_table[0], self._T_table[1])
+        self._T_fresh = True
+        if eager:
+            self._T_event = None
+        else:
+            self._T_event = torch.cuda.Event()
+            self._T_event.record()
+
+    def shadow_T(self, t):
+        """bf16 transposed shadow of a 2-D weight [R, C] -> [C, R], or of a 3x3 conv weight (physically [co][tap][ci])
+        -> [ci][tap][co]: the B operand with which the input-gradient GEMM runs row-major x row-major."""
+        if self.flat_t is None:
+            raise S4FError('transposed shadows exist in bf16 mode only')
+        e = self.entry(t)
+        if e.off not in self._T_items:
+            if e.cl:
+                co, ci = e.shape[0], e.shape[1]
+                dims = (co, 9, ci)
+            elif len(e.shape) == 2:
+                dims = (e.shape[0], 1, e.shape[1])
+            else:
+                raise S4FError(f'shadow_T: unsupported parameter shape {e.shape}')
+            if dims[0] % 64 or dims[2] % 64:
+                raise S4FError(f'shadow_T: dims {dims} are not multiples of 64')
+            if self.flat_T is None:
+                self.flat_T = torch.zeros(self.total, device=self.flat.device, dtype=torch.bfloat16)
+            self._T_items[e.off] = dims
+            self._T_table = None
+            self._T_fresh = False
+            e.v_T = self.flat_T[e.off:e.off + e.numel]
+        if not self._T_fresh:
+            self.sync_shadow()
+            self.sync_T()
+        elif self._T_event is not None:
+            torch.cuda.current_stream().wait_event(self._T_event)
+        return e.v_T
 
     def sync_shadow(self):
         """refresh the bf16 shadow if anything but our own fused kernels touched the masters"""
@@ -192,6 +255,7 @@ class ParamStore:
             K.cast(self.flat, self.flat_t, BF16)
             self._shadow_dirty = False
             self._versions = v
+            self._T_fresh = False
 
     def node_done(self):
         """called by every autograd node of this replica at the end of its backward (hook for the data-parallel

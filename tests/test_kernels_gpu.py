@@ -489,7 +489,7 @@ def test_ema_sgd(K, code):
 
 
 # ------------------------------------------------------------------------------------------------ 256-row LDS-DMA kernel
-@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6, 7, 8, 9, 10])
 def test_gemm2_dense_modes(K, hint):
     code = 1
     M, N, K_ = 1000, 768, 832
@@ -526,7 +526,7 @@ def test_gemm2_dense_modes(K, hint):
     assert float(o21[:, 21:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('hint', [3, 4, 7, 8, 9])
+@pytest.mark.parametrize('hint', [3, 4, 7, 8, 9, 10])
 @pytest.mark.parametrize('M', [2 * 1025, 2 * 1025 + 6, 512 + 16, 256 + 1, 256 + 17, 255])
 def test_gemm2_folded_tail(K, hint, M):
     """token GEMMs have M = B * 1025: a row remainder <= 16 is folded into the last tile row (hints 3/4/8/9), 17 is not;
@@ -570,6 +570,36 @@ def test_gemm2_folded_tail(K, hint, M):
     check(o4, ref, code, f'folded tail split-K hint {hint} M {M}')
 
 
+@pytest.mark.parametrize('hint', [4, 10])
+@pytest.mark.parametrize('M,N,K_', [(1024 + 16, 768, 4096), (777, 512, 2304 + 64)])
+def test_gemm_long_k_pipeline(K, hint, M, N, K_):
+    """many K-tiles through the LDS rings (counted-vmcnt pipeline of hint 10: 64 / 37 K-tiles, odd count included), several
+    launches with different data into the same buffers: a stale or early-read stage shows up as a wrong tile"""
+    code = 1
+    for seed in (1, 2, 3):
+        x, w = q(rnd(M, K_, seed=seed), code), q(rnd(N, K_, seed=10 + seed, scale=0.05), code)
+        out = torch.empty(M, N, device='cuda')
+        K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, out_f32=out, ldo_f32=N, tile_hint=hint)
+        check(out, x @ w.t(), code, f'long-K NT hint {hint} seed {seed}', tol=1e-2)
+
+
+def test_transpose_many(K):
+    """batched [R][T][C] -> [C][T][R] bf16 transposes (linear weights T = 1, conv weights T = 9): bit-exact"""
+    shapes = [(768, 1, 2304), (256, 9, 768), (64, 1, 64), (3072, 1, 768), (256, 9, 256)]
+    src = torch.randn(sum(r * t * c for r, t, c in shapes) + 64 * len(shapes), device='cuda').to(torch.bfloat16)
+    dst = torch.zeros_like(src)
+    items, off, tiles = [], 0, 0
+    for (R, T, C) in shapes:
+        items.append((off, off, R, T, C, tiles))
+        tiles += T * (R // 64) * (C // 64)
+        off += R * T * C + 64
+    dev_items = torch.tensor([v for it in items for v in it], dtype=torch.int64, device='cuda')
+    K.transpose_many(src, dst, dev_items, items)
+    for (so, do, R, T, C, _) in items:
+        ref = src[so:so + R * T * C].view(R, T, C).permute(2, 1, 0).contiguous()
+        assert torch.equal(dst[do:do + R * T * C].view(C, T, R), ref), (R, T, C)
+
+
 @pytest.mark.parametrize('code', DTYPES)
 def test_wgrad_grouped(K, code, monkeypatch):
     """the four weight-gradient GEMMs of an encoder layer in one launch (bf16) == four separate ones"""
@@ -598,7 +628,7 @@ def test_wgrad_grouped(K, code, monkeypatch):
                     check(o, ref, code, f'grouped wgrad hint {hint} sk {sk} {M}x{N}')
 
 
-@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6, 7, 10])
 @pytest.mark.parametrize('Cin,Cout', [(768, 256), (256, 256)])
 def test_gemm2_conv_modes(K, hint, Cin, Cout):
     code = 1

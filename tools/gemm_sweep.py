@@ -46,6 +46,18 @@ def tn(M, N, R, hint, sk):
 
 
 which = sys.argv[1] if len(sys.argv) > 1 else 'nt'
+if which == 'ksweep':     # fixed (prologue + epilogue) vs per-K-tile cost: time(K) at 3 full rounds of tiles
+    for Kd in (128, 256, 512, 768, 1536, 3072):
+        row = []
+        for h in (4, 10, 11, 12):
+            us = nt(16384, 3072, Kd, h)
+            row.append(f'h{h} {us:7.1f}us')
+        print(f'nt M=16384 N=3072 K={Kd:5d} | ' + ' | '.join(row), flush=True)
+    sys.exit(0)
+if which == 'big':
+    for (M, N, Kd) in ((8192, 8192, 4096), (4096, 4096, 4096), (16384, 3072, 768)):
+        print(f'nt M={M} N={N} K={Kd} | ' + ' | '.join(f'h{h} {nt(M, N, Kd, h):8.1f}us {2.0 * M * N * Kd / nt(M, N, Kd, h) / 1e6:6.0f}TF' for h in (3, 4, 10)), flush=True)
+    sys.exit(0)
 if which in ('nt', 'nn'):
     f = nt if which == 'nt' else nn
     for M in (16384, 16400, 8192, 8200):
@@ -53,7 +65,7 @@ if which in ('nt', 'nn'):
             if which == 'nn' and (N, Kd) == (2304, 768):
                 N, Kd = 768, 2304
             row = []
-            for hint in (1, 2, 3, 4) + ((8, 9) if N % 192 == 0 else ()):
+            for hint in (1, 2, 3, 4) + ((8, 9) if N % 192 == 0 else ()) + ((10,) if which == 'nt' else ()):
                 if hint in (3, 4) and N % 256:
                     continue
                 us = f(M, N, Kd, hint)
