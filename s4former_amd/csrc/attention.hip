@@ -126,7 +126,7 @@ template <typename T, int NT> struct TilePF {
 // block = NW waves x 32 queries; K/V tiles of 64 keys double-buffered in LDS, the next tile is fetched into
 // registers while the current one is consumed (one barrier per tile).
 template <typename T, int NW, bool HAS_BIAS>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void attn_fwd_kernel(const AttnArgs a) {
   using C = ACfg<T>;
   constexpr int NT = 64 * NW;
   constexpr int BUF = 2 * C::TILE_BYTES + 64 * 4;
@@ -179,6 +179,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
   fetch(0);
   commit(0);
   __syncthreads();
+  // waves whose 32 queries all lie beyond N (N = 1025: three of the 36 waves of a head) only help with the tile loads
+  const bool active = q0 < N;
 
   for (int t = 0; t < ntile; ++t) {
     const int k0 = t * 64;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
     const float* us = reinterpret_cast<const float*>(Ks + 2 * C::TILE_BYTES);
     const bool more = t + 1 < ntile;
     if (more) fetch(t + 1);
-
+    if (active) {
     f32x4 st[4][2];
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -277,6 +279,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mma16(pa[qt], fv, o[qt][dt]);
       }
+    }
     }
     if (more) commit((t + 1) & 1);
     __syncthreads();
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
   commit(0);
   __syncthreads();
 
+  const bool active = q0 < N;          // see attn_fwd_kernel
   for (int t = 0; t < ntile; ++t) {
     const int k0 = t * 64;
     const char* Ks = smem + (t & 1) * BUF;
@@ -394,6 +398,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
     const float* us = reinterpret_cast<const float*>(Ks + 2 * C::TILE_BYTES);
     const bool more = t + 1 < ntile;
     if (more) fetch(t + 1);
+    if (active) {
 
     f32x4 st[4][2], dp[4][2];
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -447,6 +452,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) dq[qt][dt] = mma16(pa[qt], fk, dq[qt][dt]);
       }
+    }
     }
     if (more) commit((t + 1) & 1);
     __syncthreads();
@@ -530,6 +536,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
   commit(0);
   __syncthreads();
 
+  const bool active = key0 < N;        // waves whose 32 keys lie beyond N only help with the tile loads
   for (int t = 0; t < ntile; ++t) {
     const int q0 = t * 64;
     const char* Qs = smem + (t & 1) * BUF;
@@ -539,6 +546,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
     const float* flgs = dels + 64;
     const bool more = t + 1 < ntile;
     if (more) fetch(t + 1);
+    if (active) {
     const bool ragged = (q0 + 64 > N);
 
 #pragma unroll
@@ -601,6 +609,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
           dk[kt][dt] = mma16(da[kt], fqq, dk[kt][dt]);
         }
       }
+    }
     }
     if (more) commit((t + 1) & 1);
     __syncthreads();

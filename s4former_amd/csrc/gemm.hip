@@ -326,6 +326,8 @@ int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn);   // gemm2.hi
 int s4f_gemm4_try(const s4f_gemm_desc& d, hipStream_t st);
 int s4f_gemm3_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm3.hip
 int s4f_gemm5_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm5.hip
+int s4f_gemm6_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm6.hip
+int s4f_gemm6_grouped_try(const s4f_gemm_desc* ds, int count, hipStream_t st);
 
 // 0 -> 128x128 kernel, 128 / 256 -> BN of the 256-row LDS-DMA kernel
 static int pick_tile(const s4f_gemm_desc& d) {
@@ -384,7 +386,7 @@ S4F_API int s4f_gemm(const s4f_gemm_desc* dp, s4f_stream stream) {
   int rc = -100;
   if (bn == 512) rc = s4f_gemm3_try(d, (hipStream_t)stream);
   else if (bn == 1024) rc = s4f_gemm4_try(d, (hipStream_t)stream);
-  else if (bn == 2048) rc = s4f_gemm5_try(d, (hipStream_t)stream);
+  else if (bn == 2048) rc = d.a_mode == S4F_OP_K ? s4f_gemm6_try(d, (hipStream_t)stream) : s4f_gemm5_try(d, (hipStream_t)stream);
   else if (bn) rc = s4f_gemm2_try(d, (hipStream_t)stream, bn);
   if (rc == -100) rc = d.dtype == S4F_BF16 ? dispatch<bf16_t>(d, (hipStream_t)stream) : dispatch<float>(d, (hipStream_t)stream);
   if (rc == -100) S4F_FAIL(-2, "s4f_gemm: unsupported operand mode pair (%d, %d)", d.a_mode, d.b_mode);
@@ -405,7 +407,7 @@ S4F_API int s4f_gemm_grouped(const s4f_gemm_desc* descs, int count, s4f_stream s
   }
   const s4f_gemm_desc& d0 = descs[0];
   bool groupable = same && count > 1 && d0.dtype == S4F_BF16 && d0.a_mode == S4F_OP_K && d0.b_mode == S4F_OP_K &&
-                   d0.tile_hint >= 2 && d0.tile_hint <= 4;
+                   ((d0.tile_hint >= 2 && d0.tile_hint <= 4) || d0.tile_hint == 10);
   for (int i = 0; i < count && groupable; ++i) {
     const s4f_gemm_desc& d = descs[i];
     groupable = d.atomic && d.out_f32 && !d.out_t && !d.out_pre && d.act == S4F_ACT_NONE && !d.bias && !d.resid && !d.pos &&
@@ -413,7 +415,8 @@ S4F_API int s4f_gemm_grouped(const s4f_gemm_desc* descs, int count, s4f_stream s
                 (d.tile_hint == 2 || d.N % 256 == 0);
   }
   if (groupable) {
-    const int rc = s4f_gemm2_grouped_try(descs, count, (hipStream_t)stream);
+    const int rc = d0.tile_hint == 10 ? s4f_gemm6_grouped_try(descs, count, (hipStream_t)stream)
+                                      : s4f_gemm2_grouped_try(descs, count, (hipStream_t)stream);
     if (rc != -100) {
       S4F_LAUNCH_CHECK();
       return rc;

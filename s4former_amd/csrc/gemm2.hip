@@ -33,6 +33,8 @@ struct GemmArgs {
   int nk_per_split;
   int tiles_m, tiles_n;
   int tail_rows;                                   // rows folded into the last tile row (0: none)
+  int zgroup;                                      // split-K blocks of one k-range are placed on one XCD (0: off)
+  int sk;                                          // number of k-ranges
 };
 
 constexpr int BM = 256, BK = 64;
@@ -566,7 +568,19 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, c
 
 template <int BN, int AMODE, int BMODE, int NW>
 __global__ __launch_bounds__(64 * NW) void gemm2_kernel(const GemmArgs args) {
-  gemm2_body<BN, AMODE, BMODE, NW>(args, blockIdx.x, blockIdx.z);
+  int bx = blockIdx.x, bz = blockIdx.z;
+  if (args.zgroup) {
+    // Conv weight gradient: 9 output tiles (one per filter tap) x many k-ranges.  The nine taps of ONE k-range read the
+    // same dy rows and (shifted by at most one image row) the same x rows: put them on one XCD so that its L2 serves
+    // eight of the nine reads.  Blocks are dealt round-robin over the XCDs in linear-id order (a speed assumption only).
+    const int nt = args.tiles_m * args.tiles_n;
+    const int lin = blockIdx.x + nt * blockIdx.z;
+    const int xcd = lin & 7, idx = lin >> 3;
+    bx = idx % nt;
+    bz = (idx / nt) * 8 + xcd;
+    if (bz >= args.sk) return;
+  }
+  gemm2_body<BN, AMODE, BMODE, NW>(args, bx, bz);
 }
 
 // Up to four independent problems of the same operand modes in one grid (the four weight-gradient GEMMs of an encoder
@@ -628,6 +642,8 @@ int launch(const s4f_gemm_desc& d, hipStream_t st) {
   a.nk_per_split = ceil_div(a.nk, sk);
   sk = ceil_div(a.nk, a.nk_per_split);
   set_tiles<BN, AM, NW>(a);
+  a.sk = sk;
+  a.zgroup = (BMo == S4F_OP_K_CONV && sk > 1) ? 1 : 0;
   const size_t shm = smem_bytes<BN, AM, BMo, NW>();
   static bool attr_set = false;
   auto kern = gemm2_kernel<BN, AM, BMo, NW>;
@@ -635,7 +651,7 @@ int launch(const s4f_gemm_desc& d, hipStream_t st) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
-  dim3 grid(a.tiles_m * a.tiles_n, 1, sk);
+  dim3 grid(a.tiles_m * a.tiles_n, 1, a.zgroup ? 8 * ceil_div(sk, 8) : sk);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), shm, st, a);
   return 0;
 }
@@ -654,6 +670,8 @@ int launch_grouped(const s4f_gemm_desc* ds, int count, hipStream_t st) {
     a.nk_per_split = ceil_div(a.nk, sk);
     sk = ceil_div(a.nk, a.nk_per_split);
     set_tiles<BN, AM, NW>(a);
+    a.sk = sk;
+    a.zgroup = 0;
     if (i < count) {
       total += a.tiles_m * a.tiles_n;
       if (sk > zmax) zmax = sk;

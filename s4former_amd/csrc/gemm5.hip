@@ -380,6 +380,8 @@ int launch5(const s4f_gemm_desc& d, hipStream_t st) {
   a.nk_per_split = ceil_div(a.nk, sk);
   sk = ceil_div(a.nk, a.nk_per_split);
   a.tiles_n = ceil_div(d.N, 256);
+  a.sk = sk;
+  a.zgroup = 0;
   const int rem = d.M % BM;
   if (AMODE == S4F_OP_ROW && rem > 0 && rem <= TAIL_MAX && d.M > BM) {
     a.tiles_m = d.M / BM;

@@ -98,6 +98,9 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
                 hints += [8, 9]                      # 256 x 192 tiles: N = 768 / 2304 -> 4 / 12 tile columns
             if N % 256 == 0 and K % 64 == 0 and b_mode == OP_ROW and a_mode in (OP_ROW, OP_ROW_CONV) and splitk == 1:
                 hints += [10]                        # 8-wave ping-pong kernel (wins from K ~ 1536 up)
+            if a_mode == OP_K and N % 256 == 0 and (b_mode == OP_K or (b_mode == OP_K_CONV and conv[3] % 256 == 0)) \
+                    and out_t is None and act == ACT_NONE:
+                hints += [10]                        # weight-gradient form of the ping-pong kernel (gemm6.hip)
             bk = 64
             nk = (K + bk - 1) // bk
             sks = sorted({max(1, min(nk, s_)) for s_ in ((splitk // 2, splitk, splitk * 2, splitk * 4) if atomic else (splitk,))})
@@ -215,7 +218,8 @@ def wgrad_grouped(problems, dtype):
     if choice is None:
         tmps = [torch.empty_like(o) for o in outs]
         sks = sorted({base, base * 2, base * 3, base * 4, max(1, base // 2)})
-        choice = _tune_gemm(sig, lambda h, sk: launch(h, sk, tmps), [(h, sk) for h in (2, 3, 4) for sk in sks])
+        hs = (2, 3, 4) + ((10,) if all(pr[3] % 256 == 0 for pr in problems) else ())
+        choice = _tune_gemm(sig, lambda h, sk: launch(h, sk, tmps), [(h, sk) for h in hs for sk in sks])
     launch(choice[0], choice[1], outs)
 
 

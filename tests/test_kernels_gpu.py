@@ -600,6 +600,20 @@ def test_transpose_many(K):
         assert torch.equal(dst[do:do + R * T * C].view(C, T, R), ref), (R, T, C)
 
 
+@pytest.mark.parametrize('hint', [4, 10])
+def test_gemm_tn_long_k(K, hint):
+    """weight-gradient form over many K-tiles incl. a ragged last one (rows = 16 * 1025 + 7), split-K and plain"""
+    code = 1
+    rows, M, N = 16 * 1025 + 7, 768, 512
+    dy, x = q(rnd(rows, M, seed=1, scale=0.2), code), q(rnd(rows, N, seed=2, scale=0.2), code)
+    ref = dy.t() @ x
+    for sk in (1, 5):
+        out = torch.zeros(M, N, device='cuda')
+        K.gemm(dev(dy, code), dev(x, code), M, N, rows, M, N, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=out, ldo_f32=N,
+               atomic=True, splitk=sk, tile_hint=hint)
+        check(out, ref, code, f'TN long-K hint {hint} splitk {sk}', tol=1e-2)
+
+
 @pytest.mark.parametrize('code', DTYPES)
 def test_wgrad_grouped(K, code, monkeypatch):
     """the four weight-gradient GEMMs of an encoder layer in one launch (bf16) == four separate ones"""
@@ -619,7 +633,7 @@ def test_wgrad_grouped(K, code, monkeypatch):
     if code == 1:
         # every (tile variant, split-K) the tuner may choose, incl. more splits than a problem has k-steps
         import s4former_amd.kernels as KK
-        for hint in (2, 3, 4):
+        for hint in (2, 3, 4, 10):
             for sk in (1, 3, 40):
                 monkeypatch.setattr(KK, '_TUNED', {('wgrad_grouped',) + tuple((M, N, rows) for (M, N) in shapes): (hint, sk)})
                 outs = [dev(torch.zeros(M, N)) for (M, N) in shapes]

@@ -20,6 +20,16 @@ if what == 'conv4':
     y = torch.empty(Mp, cout, device='cuda', dtype=T)
     def run():
         K.gemm(x, w, Mp, cout, 9 * cin, cin, 9 * cin, 1, a_mode=K.OP_ROW_CONV, out_t=y, ldo_t=cout, conv=(B, hw, hw, cin, 1), tile_hint=hint)
+elif what.startswith('convw'):   # convw:hw:cin:cout:splitk   conv weight gradient at B = 8
+    _, hw, cin, cout, sk = what.split(':'); hw, cin, cout, sk = int(hw), int(cin), int(cout), int(sk)
+    Mp = B * hw * hw
+    x = torch.randn(Mp, cin, device='cuda').to(T)
+    dy = torch.randn(Mp, cout, device='cuda').to(T)
+    dw = torch.zeros(cout, 9 * cin, device='cuda')
+    def run():
+        K.gemm(dy, x, cout, 9 * cin, Mp, cout, cin, 1, a_mode=K.OP_K, b_mode=K.OP_K_CONV, out_f32=dw, ldo_f32=9 * cin, atomic=True,
+               splitk=sk, conv=(B, hw, hw, cin, 1), tile_hint=hint)
+    print('GFLOP', 2.0 * Mp * cout * 9 * cin / 1e9)
 elif what in ('attn', 'attnb'):
     Bn, N, H = 16, 1025, 12
     qkv = torch.randn(Bn, N, 3 * 768, device='cuda').to(T)
