@@ -106,21 +106,23 @@ struct KFeeder {
   }
 };
 
-// fragment of 16 columns (col0 .. col0 + 15 of the 256-column operand image) x 32 k (s-th half of the K-tile), KMAP_TR
-__device__ __forceinline__ void frag_kp(Frag<bf16_t>& f, const char* img, int col0, int s) {
-  const int l = threadIdx.x & 63, g = l >> 4, li = l & 15, q = li >> 2, p = li & 3;
-  const int cb = col0 >> 6;
-  const int c = ((col0 & 63) >> 3) + (p >> 1);
-  s16x4 r[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int row = s * 32 + 16 * u + 4 * g + q;
-    const int pos = (((c >> 1) ^ ((row >> 1) & 3)) << 1) | (c & 1);
-    const char* a = img + cb * 8192 + row * 128 + pos * 16 + (p & 1) * 8;
-    r[u] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
-  }
-  union { s16x4 s2[2]; bf16x8 b; } cv;
-  cv.s2[0] = r[0]; cv.s2[1] = r[1];
+// Transposed fragment reads as INLINE ASM: for the ds_read_tr builtin hipcc (ROCm 7.2) cannot tell the read apart from the
+// LDS-DMA writes in flight and puts s_waitcnt vmcnt(0) in front of every group of reads, which drains the ring each
+// phase (2 x slower).  The waits are placed by hand instead: counted vmcnt + barrier before (see gemm5.hip), lgkmcnt(0)
+// + sched_barrier(0) before the MFMAs (guide rule 18).
+typedef __attribute__((ext_vector_type(2))) int i32x2;
+template <int OFF>
+__device__ __forceinline__ i32x2 lds_tr_read(unsigned addr) {
+  i32x2 r;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+  return r;
+}
+// fragment (16 columns x 32 k, KMAP_TR) = two reads 16 k-rows apart; OFF = byte offset of the 32-k step / column block
+template <int OFF>
+__device__ __forceinline__ void frag_tr(Frag<bf16_t>& f, unsigned base) {
+  union { i32x2 h[2]; bf16x8 b; } cv;
+  cv.h[0] = lds_tr_read<OFF>(base);
+  cv.h[1] = lds_tr_read<OFF + 16 * 128>(base);
   f.v = cv.b;
 }
 
@@ -164,17 +166,39 @@ __device__ __forceinline__ void g6_body(const GemmArgs& args, const int tm, cons
 
   Frag<bf16_t> a[4][2], bl[2][2], bh[2][2];
 
-  auto read_a = [&](const char* As, int half) {       // 64 rows (m) x 64 k of this wave's 128-row half
+  // per-lane base addresses of the fragment reads: lane (g, q, p) reads k-row 4 g + q (+ 16 u + 32 s: immediate), 8 bytes
+  // at columns 4 p .. 4 p + 3 of its 16-column sub-tile; the swizzle term depends on the k-row only through (row >> 1) & 3
+  const int q4 = li >> 2, p4 = li & 3;
+  const int row0 = 4 * g + q4, fsw = (row0 >> 1) & 3;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned abase[4], bbase[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+  for (int i = 0; i < 4; ++i)          // A: column block 2 wr (+ half: immediate), 16-B chunk pair i
+    abase[i] = lds0 + (2 * wr) * 8192 + row0 * 128 + ((((i ^ fsw) << 1) | (p4 >> 1)) << 4) + (p4 & 1) * 8;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) frag_kp(a[i][s], As, wr * 128 + half * 64 + i * 16, s);
+  for (int j = 0; j < 2; ++j)          // B: column block wc >> 1 (+ 2 half: immediate), chunk pair 2 (wc & 1) + j
+    bbase[j] = lds0 + G6_OPB + (wc >> 1) * 8192 + row0 * 128 + (((((2 * (wc & 1) + j) ^ fsw) << 1) | (p4 >> 1)) << 4) + (p4 & 1) * 8;
+  auto read_a = [&](auto bufc, auto halfc) {         // 64 rows (m) x 64 k of this wave's 128-row half
+    constexpr int OFF = decltype(halfc)::value * 8192;           // (the 16-bit offset field cannot reach buffer 1)
+    constexpr unsigned BOFF = decltype(bufc)::value * G6_BUF;
+    static_for<2>([&](auto sc) {
+      constexpr int S = decltype(sc)::value;
+      static_for<4>([&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+        frag_tr<OFF + S * 32 * 128>(a[I][S], abase[I] + BOFF);
+      });
+    });
   };
-  auto read_b = [&](Frag<bf16_t> (&b)[2][2], const char* Bs, int half) {   // this wave's 32 columns of one 128-column half
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) frag_kp(b[j][s], Bs, half * 128 + wc * 32 + j * 16, s);
+  auto read_b = [&](Frag<bf16_t> (&b)[2][2], auto bufc, auto halfc) {   // this wave's 32 columns of one 128-column half
+    constexpr int OFF = decltype(halfc)::value * 16384;
+    constexpr unsigned BOFF = decltype(bufc)::value * G6_BUF;
+    static_for<2>([&](auto sc) {
+      constexpr int S = decltype(sc)::value;
+      static_for<2>([&](auto jc) {
+        constexpr int J = decltype(jc)::value;
+        frag_tr<OFF + S * 32 * 128>(b[J][S], bbase[J] + BOFF);
+      });
+    });
   };
   auto mma_quad = [&](auto ahc, auto bhc, const Frag<bf16_t> (&b)[2][2]) {
     constexpr int AH = decltype(ahc)::value, BH = decltype(bhc)::value;
@@ -206,23 +230,21 @@ __device__ __forceinline__ void g6_body(const GemmArgs& args, const int tm, cons
     constexpr int BUF = decltype(bufc)::value;
     char* cur = smem + BUF * G6_BUF;
     char* nxt = smem + (BUF ^ 1) * G6_BUF;
-    const char* As = cur;
-    const char* Bs = cur + G6_OPB;
     // phase 1: quadrant (AL, BL); DMA BH(kt + 1)
-    read_a(As, 0);
-    read_b(bl, Bs, 0);
+    read_a(bufc, I0{});
+    read_b(bl, bufc, I0{});
     fb.template issue<1>(kt + 1, nxt + G6_OPB);
     seg_begin();
     mma_quad(I0{}, I0{}, bl);
     seg_end();
     // phase 2: quadrant (AL, BH); DMA AH(kt + 1)
-    read_b(bh, Bs, 1);
+    read_b(bh, bufc, I1{});
     fa.template issue<1>(kt + 1, nxt);
     seg_begin();
     mma_quad(I0{}, I1{}, bh);
     seg_end();
     // phase 3: quadrant (AH, BH); DMA AL(kt + 2)
-    read_a(As, 1);
+    read_a(bufc, I1{});
     fa.template issue<0>(kt + 2, cur);
     seg_begin();
     mma_quad(I1{}, I1{}, bh);
