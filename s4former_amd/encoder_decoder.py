@@ -20,7 +20,7 @@ from . import kernels as K
 from . import runtime
 from ._lib import S4FError
 from .base_module import BaseModule
-from .functional import LOGIT_LD, join_side_streams, on_head_stream
+from .functional import LOGIT_LD, ZERO_POOL, join_side_streams, on_head_stream
 from .params import ParamStore
 from .registry import SEGMENTORS, build_backbone, build_head, build_neck
 
@@ -314,6 +314,7 @@ class EncoderDecoder(BaseSegmentor):
         if not img.is_cuda:
             raise S4FError('the S4Former step runs on the MI355X HIP kernels only: move model and batch to the GPU')
         self.ensure_engine(img.device)
+        ZERO_POOL.begin(img.device)
         current_iter = kwargs.pop('iter')
         self.current_iter = current_iter
         kwargs.update({'img': img, 'img_metas': img_metas, 'tag': [meta['tag'] for meta in img_metas]})

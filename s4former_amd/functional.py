@@ -125,6 +125,39 @@ def _T(code):
     return torch.bfloat16 if code == BF16 else torch.float32
 
 
+class _ZeroPool:
+    """The step needs ~60 small zero-initialised fp32 accumulators (BN sums, loss sums, column sums).  One buffer,
+    re-zeroed with ONE kernel at the start of forward_train, hands out slices instead of ~60 fill launches.  A slice is
+    valid until the next step begins; nothing that outlives the step may alias it."""
+    ELEMS = 1 << 18
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def begin(self, device):
+        device = torch.device(device)
+        if self.buf is None or self.buf.device != device:
+            self.buf = torch.zeros(self.ELEMS, device=device)
+        elif self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+
+    def take(self, n, device):
+        n_al = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != torch.device(device) or self.off + n_al > self.ELEMS:
+            return torch.zeros(n, device=device)
+        v = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return v
+
+
+ZERO_POOL = _ZeroPool()
+
+
+def zeros_small(n, device):
+    return ZERO_POOL.take(n, device)
+
+
 def _splitk(tiles, nk, target=512):
     sk = max(1, target // max(1, tiles))
     return int(max(1, min(sk, max(1, nk // 4))))
@@ -310,7 +343,7 @@ class LayerFn(Function):
         del dqkv, dz
         g0 = torch.empty(Bn, N, E, device=dev)
         g0t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
-        g0cs = torch.zeros(E, device=dev)
+        g0cs = zeros_small(E, dev)
         K.layernorm_bwd(dxn, sv['x'], sv['mean1'], sv['rstd1'], store.phys(gm1), g1, g0, g0t, store.grad_phys(gm1),
                         store.grad_phys(b1), M, E, code, dcolsum=g0cs)
         # reused by the previous layer if autograd hands this very tensor through unmodified (autograd may
@@ -367,7 +400,7 @@ def head_forward(tokens, hp, store, training, save):
         mean = torch.empty(Cc, device=dev); rstd = torch.empty(Cc, device=dev)
         count = float(Mp) * world
         if training:
-            sums = torch.zeros(2 * Cc, device=dev)
+            sums = zeros_small(2 * Cc, dev)
             K.bn_stats(y, Mp, Cc, sums, code)
             if world > 1:
                 dist.all_reduce(sums)
@@ -418,7 +451,7 @@ def head_backward(dlo, dlo_t, sv, hp, store):
         Cc, h, w, s, cin_k = st['Cc'], st['h'], st['w'], st['s'], st['cin']
         Mk = Bn * h * w
         g = torch.empty(Mk, Cc, device=dev, dtype=T)
-        bsums = torch.zeros(2 * Cc, device=dev)
+        bsums = zeros_small(2 * Cc, dev)
         K.bn_relu_up_bwd(dcur, st['y'], st['scale'], st['shift'], st['mean'], st['rstd'], g, bsums, Bn, h, w, Cc, s, code)
         K.bn_param_grads(bsums, store.grad_phys(cv['bn_w']), store.grad_phys(cv['bn_b']), Cc)
         if world > 1:
@@ -450,7 +483,8 @@ def head_backward(dlo, dlo_t, sv, hp, store):
                    conv=(Bn, h, w, Cc, -1))
         del dy
     gh, gw = hp['grid']
-    dtok = torch.zeros(Bn, ntok, E, device=dev)
+    dtok = torch.empty(Bn, ntok, E, device=dev)
+    dtok[:, 0].zero_()                               # the head drops the cls row: only it needs zeros, the rest is written below
     K.layernorm_bwd(dcur, tokens[:, 1:], sv['mean0'], sv['rstd0'], store.phys(hp['norm_w']), None, dtok[:, 1:], None,
                     store.grad_phys(hp['norm_w']), store.grad_phys(hp['norm_b']), Bn * gh * gw, E, code,
                     rows_per_img=gh * gw, in_batch_stride=ntok * E)
@@ -469,7 +503,7 @@ class HeadLossFn(Function):
         if tuple(labels_u8.shape) != (Bn, H, W):
             raise S4FError(f'labels {tuple(labels_u8.shape)} do not match the logits size {(Bn, H, W)} '
                            '(the identity resize of decode_head.py:322-326 is the only one on the hot path)')
-        loss_sum = torch.zeros(1, device=tokens.device)
+        loss_sum = zeros_small(1, tokens.device)
         # logsumexp per pixel is kept for the backward (4 B / pixel) so that it does not re-normalise the softmax
         lse = torch.empty(Bn, H, W, device=tokens.device) if need_grad and s in (2, 4) else None
         K.upce_fwd(logits, labels_u8, loss_sum, Bn, h, w, hp['num_classes'], LOGIT_LD, s, hp['ignore_index'], lse_out=lse)
