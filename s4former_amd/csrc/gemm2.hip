@@ -242,6 +242,11 @@ __device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, i
   }
 }
 
+#ifdef S4F_EPI_NT
+#define EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define EPI_STORE(ptr, val) (*(ptr) = (val))
+#endif
 // One pass of the coalesced epilogue: 128 staged fp32 rows (tile, row stride BN + 4) -> global, 16 B per lane.
 // mrow0 = global row of staged row 0; rows >= M are skipped.
 template <int BN, int NW>
@@ -306,7 +311,7 @@ __device__ __forceinline__ void epilogue_rows(const s4f_gemm_desc& d, const floa
             v[e] = gy;
             pv[e] = (bf16_t)gd;
           }
-          if (out_pre) *reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n) = pv;
+          if (out_pre) EPI_STORE(reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n), pv);
         } else if (d.act == S4F_ACT_GELU_BWD) {
           const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
 #pragma unroll
@@ -327,7 +332,7 @@ __device__ __forceinline__ void epilogue_rows(const s4f_gemm_desc& d, const floa
           bf16x8 ov;
 #pragma unroll
           for (int e = 0; e < 8; ++e) ov[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x8*>(out_t + (long)m * d.ldo_t + n) = ov;
+          EPI_STORE(reinterpret_cast<bf16x8*>(out_t + (long)m * d.ldo_t + n), ov);
         }
       }
     }

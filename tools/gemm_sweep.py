@@ -49,8 +49,8 @@ which = sys.argv[1] if len(sys.argv) > 1 else 'nt'
 if which == 'ksweep':     # fixed (prologue + epilogue) vs per-K-tile cost: time(K) at 3 full rounds of tiles
     for Kd in (128, 256, 512, 768, 1536, 3072):
         row = []
-        for h in (4, 10, 11, 12):
-            us = nt(16384, 3072, Kd, h)
+        for h in (4, 8, 10):
+            us = nt(16384, 3072 if h != 8 else 2304, Kd, h)
             row.append(f'h{h} {us:7.1f}us')
         print(f'nt M=16384 N=3072 K={Kd:5d} | ' + ' | '.join(row), flush=True)
     sys.exit(0)
