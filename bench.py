@@ -236,7 +236,7 @@ def main():
             # HBM bytes per GEMM launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command
             # (separate --pmc runs, FETCH_SIZE doubled for gfx950); bench.py cannot run the profiler on itself.
             traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
-        roofline = dict(bound='mfma', kernel='gemm_kernel<T, AMODE, BMODE> (dense + implicit-GEMM conv family)',
+        roofline = dict(bound='mfma', kernel='s4f_gemm family: g2::gemm2_kernel / g5::gemm5_kernel / g6::gemm6_kernel (dense + implicit-GEMM conv, all launches of a step)',
                         achieved=round(gemm_gflop / gemm_ms, 1), peak=peak, unit='TFLOP/s',
                         frac=round(gemm_gflop / gemm_ms / peak, 4), traffic=traffic,
                         algorithmic_gflop_per_launch=round(gemm_gflop / gemm_calls, 2),
