@@ -125,6 +125,9 @@ def main():
     from s4former_amd.functional import join_side_streams
     from s4former_amd.presets import MAX_ITERS, OPTIMIZER, setr_pup_model, step_gflop, synthetic_batch
 
+    if os.environ.get('S4F_BENCH_WATCHDOG'):
+        import faulthandler                      # debugging aid: dump every thread's stack if the run stalls
+        faulthandler.dump_traceback_later(int(os.environ['S4F_BENCH_WATCHDOG']), repeat=False, exit=False)
     rank, local, world = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback on the product path)'
@@ -204,6 +207,9 @@ def main():
     # ---- live per-kernel durations (HIP events on the launch stream) for the dominant kernel
     roofline = None
     kprof = None
+    if not args.no_kernel_profile and rank != 0:
+        step(it)                                   # the profiled extra step contains collectives: every rank takes part
+        it += 1
     if rank == 0 and not args.no_kernel_profile:
         with _lib.CallProfiler() as prof:
             step(it)
