@@ -315,6 +315,7 @@ class EncoderDecoder(BaseSegmentor):
             raise S4FError('the S4Former step runs on the MI355X HIP kernels only: move model and batch to the GPU')
         self.ensure_engine(img.device)
         ZERO_POOL.begin(img.device)
+        self._student_store.step_epoch = getattr(self._student_store, 'step_epoch', 0) + 1
         current_iter = kwargs.pop('iter')
         self.current_iter = current_iter
         kwargs.update({'img': img, 'img_metas': img_metas, 'tag': [meta['tag'] for meta in img_metas]})

@@ -513,6 +513,13 @@ class HeadLossFn(Function):
             ctx.meta = (labels_u8, k, Bn, h, w, s)
             ctx.lse = lse
             ctx.consumer = GRAD_CONSUMER
+            # a head may be called several times per step (decode head: labelled + pseudo-labelled batch); its arena range
+            # is final - and handed to the gradient reducer - when the last of those calls has run its backward
+            ep = getattr(store, 'step_epoch', 0)
+            if hp.get('_epoch') != ep:
+                hp['_epoch'], hp['_pending'] = ep, 0
+            hp['_pending'] += 1
+            ctx.range = store.range_of(prm)
         return (loss_sum * k).reshape(())
 
     @staticmethod
@@ -532,4 +539,7 @@ class HeadLossFn(Function):
             dtok.record_stream(ctx.consumer)          # allocated on the head's stream, read by the backbone's
         ctx.sv = None
         store.node_done()
+        hp['_pending'] = hp.get('_pending', 1) - 1
+        if hp['_pending'] == 0:
+            store.range_done(*ctx.range)
         return (dtok, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
