@@ -156,8 +156,11 @@ def main():
     reducer.attach(model.student_store)
 
     seg_gain = 1.0
-    if n_unsup and rank == 0 or (n_unsup and world > 1):
-        seg_gain = calibrate_teacher(model, batches[0], n_sup, n_unsup, args.mask_ratio)
+    if n_unsup:
+        # every rank calibrates on the SAME batch (rank 0's): the teacher replicas stay bit-identical
+        calib = batches[0] if rank == 0 else synthetic_batch(1999, n_sup, n_unsup, img=img, num_classes=ncls, device=dev)
+        seg_gain = calibrate_teacher(model, calib, n_sup, n_unsup, args.mask_ratio)
+        del calib
 
     def step(it):
         imgs, gt, metas = batches[it % 2]
