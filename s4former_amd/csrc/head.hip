@@ -239,6 +239,65 @@ __global__ __launch_bounds__(256) void bn_relu_up_bwd_kernel(const T* __restrict
   }
 }
 
+// s = 1 (the last stage of a head: BN + ReLU without upsample): g = dy * [x*scale+shift > 0] is a pure streaming pass.
+// Four pixel rows per thread and iteration are in flight (the generic kernel has one), no index arithmetic, and a grid of
+// at most 2048 blocks keeps the 2 C final atomics per block off the critical path.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_bwd_s1_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift,
+                                                             const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                             T* __restrict__ g, float* __restrict__ sums, long npix, int C) {
+  constexpr int N = VT<T>::N;
+  constexpr int U = 4;
+  extern __shared__ float red[];          // [RL][2][C]
+  const int CPR = C / N;
+  const int RL = 256 / CPR;
+  const int cc = threadIdx.x % CPR, rl = threadIdx.x / CPR;
+  float sc[N], sh[N], mu[N], rs[N], sg[N], sgx[N];
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    sc[e] = scale[cc * N + e]; sh[e] = shift[cc * N + e]; mu[e] = mean[cc * N + e]; rs[e] = rstd[cc * N + e];
+    sg[e] = 0.f; sgx[e] = 0.f;
+  }
+  for (long p0 = (long)blockIdx.x * RL * U + rl; p0 < npix; p0 += (long)gridDim.x * RL * U) {
+    float dv[U][N], xv[U][N];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long p = p0 + (long)u * RL;
+      if (p < npix) {
+        VT<T>::load(dy + p * C + cc * N, dv[u]);
+        VT<T>::load(x + p * C + cc * N, xv[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long p = p0 + (long)u * RL;
+      if (p < npix) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float gg = (xv[u][e] * sc[e] + sh[e] > 0.f) ? dv[u][e] : 0.f;
+          dv[u][e] = gg;
+          sg[e] += gg;
+          sgx[e] += gg * (xv[u][e] - mu[e]) * rs[e];
+        }
+        VT<T>::store(g + p * C + cc * N, dv[u]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < N; ++e) {
+    red[(rl * 2 + 0) * C + cc * N + e] = sg[e];
+    red[(rl * 2 + 1) * C + cc * N + e] = sgx[e];
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * C; k += 256) {
+    const int which = k / C, c = k % C;
+    float t = 0.f;
+    for (int r = 0; r < RL; ++r) t += red[(r * 2 + which) * C + c];
+    atomicAdd(sums + which * C + c, t);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ S = 2 | 4 specialisations
 // align_corners=False by an integer factor S: output o = S*i + r reads inputs (i-1, i) with fraction (r + S/2 + .5)/S
 // when r < S/2 and (i, i+1) with fraction (r - S/2 + .5)/S otherwise; at the borders the neighbour index is clamped, which
@@ -487,6 +546,91 @@ __global__ __launch_bounds__(256) void upce_fwd_kernel(const float* __restrict__
     const float lse = mx + logf(se);
     if (lse_out) lse_out[i] = lse;
     lsum += lse - zl;
+  }
+  const float tot = block_sum_256(lsum, red);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, tot);
+}
+
+// Forward for the integer upsampling factors of the heads (S = 2: decode head, S = 4: auxiliary heads).  A thread owns
+// one LOW-res pixel and produces its S x S block of high-res pixels: the 3 x 3 low-res neighbourhood is read once per
+// output row as 16-B chunks (the per-output-pixel kernel above re-gathers 4 neighbours x 32 floats for every output
+// pixel: L1/TA-bound at 760 GB/s), interpolated separably with compile-time fractions (see up_frac / the backward),
+// and the S logit vectors of a row live in registers for the max / sum-exp / label pick.  CCH = class chunks of 4.
+template <int S, int CCH>
+__global__ __launch_bounds__(256) void upce_fwd_s_kernel(const float* __restrict__ lo, const uint8_t* __restrict__ labels,
+                                                         float* __restrict__ loss_sum, float* __restrict__ lse_out, int B,
+                                                         int h, int w, int C, int ldc, int ignore) {
+  __shared__ float red[4];
+  constexpr int PS = CCH * 4 + 4;                   // LDS pixel stride in floats (112 B for 6 chunks: conflict-free b128 reads)
+  __shared__ __attribute__((aligned(16))) float tile[18 * 18 * PS];
+  const int H = h * S, W = w * S;
+  const int tiles_x = (w + 15) >> 4, tiles_y = (h + 15) >> 4;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int tid = threadIdx.x;
+  const int j = tx * 16 + (tid & 15), i = ty * 16 + (tid >> 4);
+  // the block's 18 x 18 low-res neighbourhood (border-clamped coordinates) goes through LDS: every logit vector is read
+  // from global memory once per block instead of up to nine times per thread
+  for (int idx = tid; idx < 18 * 18 * CCH; idx += 256) {
+    const int pix = idx / CCH, c4 = idx - pix * CCH;
+    const int a = pix / 18, bb = pix - a * 18;
+    const int gr = min(max(ty * 16 - 1 + a, 0), h - 1), gc = min(max(tx * 16 - 1 + bb, 0), w - 1);
+    *reinterpret_cast<f32x4*>(tile + pix * PS + c4 * 4) =
+        *reinterpret_cast<const f32x4*>(lo + (((long)b * h + gr) * w + gc) * ldc + c4 * 4);
+  }
+  __syncthreads();
+  float lsum = 0.f;
+  if (i < h && j < w) {
+    const float* P[3][3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int n = 0; n < 3; ++n) P[m][n] = tile + (((tid >> 4) + m) * 18 + (tid & 15) + n) * PS;
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+      const int m0 = r < S / 2 ? 0 : 1;
+      const float fr = ((r < S / 2 ? r + S / 2 : r - S / 2) + 0.5f) / S;
+      float z[S][CCH * 4];
+#pragma unroll
+      for (int c4 = 0; c4 < CCH; ++c4) {
+        f32x4 L0[3], L1[3];
+#pragma unroll
+        for (int n = 0; n < 3; ++n) {
+          L0[n] = *reinterpret_cast<const f32x4*>(P[m0][n] + c4 * 4);
+          L1[n] = *reinterpret_cast<const f32x4*>(P[m0 + 1][n] + c4 * 4);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v[3];
+#pragma unroll
+          for (int n = 0; n < 3; ++n) v[n] = L0[n][e] + fr * (L1[n][e] - L0[n][e]);
+#pragma unroll
+          for (int q = 0; q < S; ++q) {
+            const float fq = ((q < S / 2 ? q + S / 2 : q - S / 2) + 0.5f) / S;
+            z[q][c4 * 4 + e] = q < S / 2 ? v[0] + fq * (v[1] - v[0]) : v[1] + fq * (v[2] - v[1]);
+          }
+        }
+      }
+      const long row = ((long)b * H + (S * i + r)) * W + S * j;
+#pragma unroll
+      for (int q = 0; q < S; ++q) {
+        const int lab = labels[row + q];
+        if (lab == ignore || lab >= C) continue;     // ignored pixels: no loss term, lse not written (the backward skips them)
+        float mx = -INFINITY, zl = 0.f;
+#pragma unroll
+        for (int c = 0; c < CCH * 4; ++c)
+          if (c < C) { mx = fmaxf(mx, z[q][c]); zl = (c == lab) ? z[q][c] : zl; }
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < CCH * 4; ++c)
+          if (c < C) se += expf(z[q][c] - mx);
+        const float lse = mx + logf(se);
+        if (lse_out) lse_out[row + q] = lse;
+        lsum += lse - zl;
+      }
+    }
   }
   const float tot = block_sum_256(lsum, red);
   if (threadIdx.x == 0) atomicAdd(loss_sum, tot);
@@ -928,6 +1072,14 @@ S4F_API int s4f_bn_relu_up_bwd(const void* dy, const void* x, const float* scale
     S4F_LAUNCH_CHECK();
     return 0;
   }
+  if (s == 1) {
+    int g1 = grid_for(npix, rl * 4 * 4);
+    if (g1 > 2048) g1 = 2048;
+    if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_relu_bwd_s1_kernel<bf16_t>, dim3(g1), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, rstd, (bf16_t*)g, sums, npix, C);
+    else hipLaunchKernelGGL(bn_relu_bwd_s1_kernel<float>, dim3(g1), dim3(256), shm, (hipStream_t)stream, (const float*)dy, (const float*)x, scale, shift, mean, rstd, (float*)g, sums, npix, C);
+    S4F_LAUNCH_CHECK();
+    return 0;
+  }
   if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_relu_up_bwd_kernel<bf16_t>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, rstd, (bf16_t*)g, sums, B, h, w, C, s);
   else hipLaunchKernelGGL(bn_relu_up_bwd_kernel<float>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const float*)dy, (const float*)x, scale, shift, mean, rstd, (float*)g, sums, B, h, w, C, s);
   S4F_LAUNCH_CHECK();
@@ -964,6 +1116,20 @@ S4F_API int s4f_upce_fwd(const float* logits_lo, const uint8_t* labels, float* l
   S4F_CHECK(logits_lo && labels && loss_sum, "s4f_upce_fwd: null pointer");
   LOGIT_CHECK("s4f_upce_fwd");
   const long total = (long)B * h * s * w * s;
+  if ((s == 2 || s == 4) && ldc >= 4 * ceil_div(C, 4)) {
+    const int nblk = B * ceil_div(h, 16) * ceil_div(w, 16);
+    hipStream_t st = (hipStream_t)stream;
+    const bool small = C <= 24;
+    if (s == 2) {
+      if (small) hipLaunchKernelGGL((upce_fwd_s_kernel<2, 6>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, loss_sum, lse_out, B, h, w, C, ldc, ignore_index);
+      else hipLaunchKernelGGL((upce_fwd_s_kernel<2, 8>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, loss_sum, lse_out, B, h, w, C, ldc, ignore_index);
+    } else {
+      if (small) hipLaunchKernelGGL((upce_fwd_s_kernel<4, 6>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, loss_sum, lse_out, B, h, w, C, ldc, ignore_index);
+      else hipLaunchKernelGGL((upce_fwd_s_kernel<4, 8>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, loss_sum, lse_out, B, h, w, C, ldc, ignore_index);
+    }
+    S4F_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(upce_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, logits_lo, labels, loss_sum, lse_out, B, h, w, C, ldc, s, ignore_index);
   S4F_LAUNCH_CHECK();
   return 0;
