@@ -81,7 +81,17 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ x, 
   const long r0 = (long)blockIdx.x * rows_per_block;
   long r1 = r0 + rows_per_block;
   if (r1 > rows) r1 = rows;
-  for (long r = r0 + rl; r < r1; r += RL) {
+  long r = r0 + rl;
+  for (; r + 3L * RL < r1; r += 4L * RL) {             // four rows in flight per thread
+    float f[4][N];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) VT<T>::load(x + (r + (long)u * RL) * C + cc * N, f[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < N; ++e) { s[e] += f[u][e]; q[e] += f[u][e] * f[u][e]; }
+  }
+  for (; r < r1; r += RL) {
     float f[N];
     VT<T>::load(x + r * C + cc * N, f);
 #pragma unroll
@@ -454,18 +464,48 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const int CPR = C / N;
   const long total = rows * CPR;
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-    const int cc = i % CPR;
-    float gv[N], xv[N], o[N];
-    VT<T>::load(g + i * N, gv);
-    VT<T>::load(x + i * N, xv);
+  // the per-channel terms are the same for every item of a thread when the grid stride is a multiple of CPR (it is: the
+  // stride is a multiple of 256 and CPR divides 256): hoisted out of the loop
+  const long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cc = i0 % CPR;
+  float a1[N], a2[N], a3[N], mu[N];
 #pragma unroll
-    for (int e = 0; e < N; ++e) {
-      const int c = cc * N + e;
-      const float xh = (xv[e] - mean[c]) * rstd[c];
-      o[e] = gamma[c] * rstd[c] * (gv[e] - sums[c] * inv_count - xh * sums[C + c] * inv_count);
+  for (int e = 0; e < N; ++e) {
+    const int c = cc * N + e;
+    const float k = gamma[c] * rstd[c];
+    mu[e] = mean[c];
+    a1[e] = k;                                     // g
+    a2[e] = -k * sums[c] * inv_count;              // constant
+    a3[e] = -k * rstd[c] * sums[C + c] * inv_count;   // (x - mean)
+  }
+  const bool hoist = (stride % CPR) == 0;
+  for (long i = i0; i < total; i += 2 * stride) {
+    float gv[2][N], xv[2][N], o[N];
+    const bool two = i + stride < total;
+    VT<T>::load(g + i * N, gv[0]);
+    VT<T>::load(x + i * N, xv[0]);
+    if (two) {
+      VT<T>::load(g + (i + stride) * N, gv[1]);
+      VT<T>::load(x + (i + stride) * N, xv[1]);
     }
-    VT<T>::store(dx + i * N, o);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      const long ii = i + u * stride;
+      if (hoist) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) o[e] = a1[e] * gv[u][e] + a2[e] + a3[e] * (xv[u][e] - mu[e]);
+      } else {
+        const int c0 = (int)(ii % CPR) * N;
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const int c = c0 + e;
+          const float xh = (xv[u][e] - mean[c]) * rstd[c];
+          o[e] = gamma[c] * rstd[c] * (gv[u][e] - sums[c] * inv_count - xh * sums[C + c] * inv_count);
+        }
+      }
+      VT<T>::store(dx + ii * N, o);
+    }
   }
 }
 
@@ -1000,7 +1040,8 @@ S4F_API int s4f_bn_stats(const void* x, int64_t rows, int C, float* sums, int dt
   CH_CHECK("s4f_bn_stats");
   const int cpr = C / (dtype == S4F_BF16 ? 8 : 4);
   const int rl = 256 / cpr;
-  int rows_per_block = 256;
+  int rows_per_block = 256;                            // at most ~1024 blocks: 2 C atomics per block into the same sums
+  if (ceil_div(rows, rows_per_block) > 1024) rows_per_block = ceil_div(rows, 1024);
   const int grid = ceil_div(rows, rows_per_block);
   const size_t shm = (size_t)rl * 2 * C * sizeof(float);
   if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)x, (long)rows, C, sums, rows_per_block);
