@@ -391,6 +391,13 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
   __syncthreads();
 
   const bool active = q0 < N;          // see attn_fwd_kernel
+  f32x4 sinit[2], dinit[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const float s0 = -lse2[qt] * (1.f / kScale2), d0 = -delq[qt];
+    sinit[qt] = f32x4{s0, s0, s0, s0};
+    dinit[qt] = f32x4{d0, d0, d0, d0};
+  }
   for (int t = 0; t < ntile; ++t) {
     const int k0 = t * 64;
     const char* Ks = smem + (t & 1) * BUF;
@@ -400,8 +407,9 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
     if (more) fetch(t + 1);
     if (active) {
 
+    // row constants as the initial accumulators (guide, attention backward): S' = q.k - lse / c and dP' = dO.v - delta
+    // leave the MFMA chains ready for p = exp2(c S' [+ bias]) and dS = p dP' (one subtraction per score less)
     f32x4 st[4][2], dp[4][2];
-    const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -411,8 +419,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
         tile_rowfrag<T>(fv, Vs, ks * 16 + li, s);
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          st[ks][qt] = mma16(fk, fq[qt][s], s == 0 ? zero4 : st[ks][qt]);
-          dp[ks][qt] = mma16(fv, fdo[qt][s], s == 0 ? zero4 : dp[ks][qt]);
+          st[ks][qt] = mma16(fk, fq[qt][s], s == 0 ? sinit[qt] : st[ks][qt]);
+          dp[ks][qt] = mma16(fv, fdo[qt][s], s == 0 ? dinit[qt] : dp[ks][qt]);
         }
       }
     const bool ragged = (k0 + 64 > N);
@@ -424,9 +432,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          const float e = HAS_BIAS ? fmaf(st[ks][qt][r], kScale2, uu[r] * flagq[qt]) - lse2[qt]
-                                   : fmaf(st[ks][qt][r], kScale2, -lse2[qt]);
-          st[ks][qt][r] = fexp2<T>(e) * (dp[ks][qt][r] - delq[qt]);
+          const float e = HAS_BIAS ? fmaf(st[ks][qt][r], kScale2, uu[r] * flagq[qt]) : st[ks][qt][r] * kScale2;
+          st[ks][qt][r] = fexp2<T>(e) * dp[ks][qt][r];
         }
       }
     }
@@ -551,8 +558,17 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
 
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
+      // row constants (-lse / c, -delta of the query rows 4 g + r) as the initial accumulators: see attn_dq_kernel
       f32x4 sc[2][2], dp[2][2];
-      const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 sini[2], dini[2];
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        const int qo = ms * 32 + qs * 16 + 4 * g;
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(lses + qo);
+        const f32x4 de = *reinterpret_cast<const f32x4*>(dels + qo);
+        sini[qs] = ls * (-1.f / kScale2);
+        dini[qs] = -de;
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -562,25 +578,23 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
           tile_rowfrag<T>(fdr, Ds, ms * 32 + qs * 16 + li, s);
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
-            sc[qs][kt] = mma16(fqr, fk[kt][s], s == 0 ? zero4 : sc[qs][kt]);
-            dp[qs][kt] = mma16(fdr, fv[kt][s], s == 0 ? zero4 : dp[qs][kt]);
+            sc[qs][kt] = mma16(fqr, fk[kt][s], s == 0 ? sini[qs] : sc[qs][kt]);
+            dp[qs][kt] = mma16(fdr, fv[kt][s], s == 0 ? dini[qs] : dp[qs][kt]);
           }
         }
 #pragma unroll
       for (int qs = 0; qs < 2; ++qs) {
         const int qo = ms * 32 + qs * 16 + 4 * g;
-        const f32x4 ls = *reinterpret_cast<const f32x4*>(lses + qo);
-        const f32x4 de = *reinterpret_cast<const f32x4*>(dels + qo);
         f32x4 fl = f32x4{1.f, 1.f, 1.f, 1.f};
         if (HAS_BIAS) fl = *reinterpret_cast<const f32x4*>(flgs + qo);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt) {
-            const float e = HAS_BIAS ? fmaf(sc[qs][kt][r], kScale2, uk[kt] * fl[r]) - ls[r] : fmaf(sc[qs][kt][r], kScale2, -ls[r]);
+            const float e = HAS_BIAS ? fmaf(sc[qs][kt][r], kScale2, uk[kt] * fl[r]) : sc[qs][kt][r] * kScale2;
             const float p = fexp2<T>(e);
             sc[qs][kt][r] = p;
-            dp[qs][kt][r] = p * (dp[qs][kt][r] - de[r]);
+            dp[qs][kt][r] = p * dp[qs][kt][r];
           }
         }
         if (ragged) {

@@ -136,3 +136,34 @@ def test_plain_mt_pseudo_loss_vs_oracle():
             r = float(p.grad.norm())
             assert abs(rec[0]['gn'][n] - r) <= 2e-3 * r + 1e-9, (n, rec[0]['gn'][n], r)
     assert abs(float(model.last_mask_ratio) - float(orc.last['mask_ratio'])) < 2e-3
+
+
+def test_transposed_shadows_follow_the_weights():
+    """bf16 mode: the transposed operand shadows the input-gradient GEMMs read (ParamStore.shadow_T) are refreshed by the
+    optimiser step and after external writes to the masters (mark_dirty); always equal to the bf16 shadow, transposed."""
+    z, meta = load_gold('sup')
+    model, opt, sched = build_product(meta, 'bf16')
+    run_product(model, opt, sched, meta, iters=1)             # one backward registers the weights; opt.step refreshes them
+    store = model.student_store
+    assert store._T_items, 'backward did not register any transposed shadow'
+    checked = 0
+    for e in store.entries:
+        if e.off not in store._T_items:
+            continue
+        R, T, Cc = store._T_items[e.off]
+        src = store.flat_t[e.off:e.off + e.numel].view(R, T, Cc)
+        dst = store.flat_T[e.off:e.off + e.numel].view(Cc, T, R)
+        assert torch.equal(dst, src.permute(2, 1, 0).contiguous()), e.name
+        checked += 1
+    assert checked >= 4
+    # external modification of a master weight -> shadow and transposed shadow follow on the next use
+    e0 = next(e for e in store.entries if e.off in store._T_items)
+    prm = e0.module._parameters[e0.attr]
+    with torch.no_grad():
+        prm.mul_(0.5)
+    store.mark_dirty()
+    t = store.shadow_T(prm)
+    torch.cuda.synchronize()
+    R, T, Cc = store._T_items[e0.off]
+    ref = store.phys(prm).to(torch.bfloat16).view(R, T, Cc).permute(2, 1, 0).contiguous().view(-1)
+    assert torch.equal(t.view(-1), ref)
