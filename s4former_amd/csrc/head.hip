@@ -324,12 +324,13 @@ template <int S> __device__ __forceinline__ float down_weight(int k, int i, int 
   return (i == n_in - 1) ? 1.f : 1.f - (k - S + 0.5f) / S;
 }
 
-// One block per low-res row (grid-strided), thread = (low-res pixel, 16-byte channel chunk): loads the 3x3 neighbourhood
-// once, applies BN + ReLU, and writes the S x S outputs of its cell.  No integer division in the pixel loop.
+// A block walks DOWN a strip of PPB low-res columns (thread = (column, 16-byte channel chunk)) over rows_per_seg rows:
+// the 3 x 3 neighbourhood of a pixel shares two of its rows with the pixel below, so they stay in registers (BN + ReLU
+// already applied) and a pixel costs 3 loads instead of 9; it writes the S x S outputs of its cell.
 template <typename T, int S>
 __global__ __launch_bounds__(256) void bn_relu_up_fwd_s_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, T* __restrict__ y, int B,
-                                                               int h, int w, int C) {
+                                                               int h, int w, int C, int rows_per_seg) {
   constexpr int N = VT<T>::N;
   const int CPR = C / N, PPB = 256 / CPR;
   const int cc = threadIdx.x % CPR, pl = threadIdx.x / CPR;
@@ -337,21 +338,29 @@ __global__ __launch_bounds__(256) void bn_relu_up_fwd_s_kernel(const T* __restri
   float sc[N], sh[N];
 #pragma unroll
   for (int e = 0; e < N; ++e) { sc[e] = scale[cc * N + e]; sh[e] = shift[cc * N + e]; }
-  const int rows = B * h;
-  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-    const int b = row / h, i = row - b * h;
-    const int rr[3] = {max(i - 1, 0), i, min(i + 1, h - 1)};
-    for (int j = pl; j < w; j += PPB) {
-      const int cj[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
-      float a[3][3][N];
+  const int nstrip = (w + PPB - 1) / PPB, nseg = (h + rows_per_seg - 1) / rows_per_seg;
+  for (int item = blockIdx.x; item < B * nseg * nstrip; item += gridDim.x) {
+    const int strip = item % nstrip;
+    const int seg = (item / nstrip) % nseg;
+    const int b = item / (nstrip * nseg);
+    const int j = strip * PPB + pl;
+    if (j >= w) continue;
+    const int cj[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
+    auto load_row = [&](int row, float (&dst)[3][N]) {
+      const long ro = ((long)b * h + min(max(row, 0), h - 1)) * w;
 #pragma unroll
-      for (int m = 0; m < 3; ++m)
+      for (int n = 0; n < 3; ++n) {
+        VT<T>::load(x + (ro + cj[n]) * C + cc * N, dst[n]);
 #pragma unroll
-        for (int n = 0; n < 3; ++n) {
-          VT<T>::load(x + (((long)b * h + rr[m]) * w + cj[n]) * C + cc * N, a[m][n]);
-#pragma unroll
-          for (int e = 0; e < N; ++e) a[m][n][e] = fmaxf(a[m][n][e] * sc[e] + sh[e], 0.f);
-        }
+        for (int e = 0; e < N; ++e) dst[n][e] = fmaxf(dst[n][e] * sc[e] + sh[e], 0.f);
+      }
+    };
+    const int i0 = seg * rows_per_seg, i1 = min(h, i0 + rows_per_seg);
+    float a[3][3][N];
+    load_row(i0 - 1, a[0]);
+    load_row(i0, a[1]);
+    for (int i = i0; i < i1; ++i) {
+      load_row(i + 1, a[2]);
 #pragma unroll
       for (int l = 0; l < S; ++l) {
         const int n0 = l < S / 2 ? 0 : 1;
@@ -371,6 +380,10 @@ __global__ __launch_bounds__(256) void bn_relu_up_fwd_s_kernel(const T* __restri
           VT<T>::store(y + (((long)b * H + S * i + r) * W + S * j + l) * C + cc * N, o);
         }
       }
+#pragma unroll
+      for (int n = 0; n < 3; ++n)
+#pragma unroll
+        for (int e = 0; e < N; ++e) { a[0][n][e] = a[1][n][e]; a[1][n][e] = a[2][n][e]; }
     }
   }
 }
@@ -380,7 +393,11 @@ __global__ __launch_bounds__(256) void bn_relu_up_bwd_s_kernel(const T* __restri
                                                                const float* __restrict__ scale, const float* __restrict__ shift,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                T* __restrict__ g, float* __restrict__ sums, int B, int h,
-                                                               int w, int C) {
+                                                               int w, int C, int rows_per_seg) {
+  // A block walks DOWN a strip of PPB low-res columns (thread = (column, 16-byte channel chunk)) over rows_per_seg
+  // low-res rows.  The 2S x 2S window of a low-res pixel overlaps the next row's window in S high-res rows: their
+  // horizontally reduced values stay in registers, so a pixel costs S * 2S loads instead of (2S)^2 (the first version
+  // was bound by the L1 / TA request rate, 2.6 TB/s of algorithmic bytes).  Same sums, same order: bit-identical.
   constexpr int N = VT<T>::N;
   constexpr int R = 2 * S;
   extern __shared__ float red[];          // [PPB][2][C]
@@ -393,51 +410,64 @@ __global__ __launch_bounds__(256) void bn_relu_up_bwd_s_kernel(const T* __restri
     sc[e] = scale[cc * N + e]; sh[e] = shift[cc * N + e]; mu[e] = mean[cc * N + e]; rs[e] = rstd[cc * N + e];
     sg[e] = 0.f; sgx[e] = 0.f;
   }
-  const int rows = B * h;
-  for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-    const int b = row / h, i = row - b * h;
-    float wy[R];
-#pragma unroll
-    for (int k = 0; k < R; ++k) wy[k] = down_weight<S>(k, i, h);
-    const int oy0 = S * i - S / 2;
-    for (int j = pl; j < w; j += PPB) {
+  const int nstrip = (w + PPB - 1) / PPB, nseg = (h + rows_per_seg - 1) / rows_per_seg;
+  for (int item = blockIdx.x; item < B * nseg * nstrip; item += gridDim.x) {
+    const int strip = item % nstrip;
+    const int seg = (item / nstrip) % nseg;
+    const int b = item / (nstrip * nseg);
+    const int j = strip * PPB + pl;
+    if (j < w) {
       float wx[R];
 #pragma unroll
       for (int l = 0; l < R; ++l) wx[l] = down_weight<S>(l, j, w);
       const int ox0 = S * j - S / 2;
-      float acc[N];
+      const T* colp[R];
 #pragma unroll
-      for (int e = 0; e < N; ++e) acc[e] = 0.f;
-      // out-of-image taps carry weight 0 and a clamped (valid) address: the 4 S^2 loads stay branch-free and independent
-#pragma unroll
-      for (int k = 0; k < R; ++k) {
-        const int oy = min(max(oy0 + k, 0), H - 1);
-        const T* rowp = dy + (((long)b * H + oy) * W) * C + cc * N;
-        float t[N];
+      for (int l = 0; l < R; ++l) colp[l] = dy + (long)min(max(ox0 + l, 0), W - 1) * C + cc * N;
+      auto hrow = [&](int oy, float (&t)[N]) {        // horizontally reduced high-res row oy (clamped: weight 0 outside)
+        const long ro = ((long)b * H + min(max(oy, 0), H - 1)) * W * C;
 #pragma unroll
         for (int e = 0; e < N; ++e) t[e] = 0.f;
 #pragma unroll
         for (int l = 0; l < R; ++l) {
-          const int ox = min(max(ox0 + l, 0), W - 1);
           float f[N];
-          VT<T>::load(rowp + (long)ox * C, f);
+          VT<T>::load(colp[l] + ro, f);
 #pragma unroll
           for (int e = 0; e < N; ++e) t[e] += wx[l] * f[e];
         }
+      };
+      const int i0 = seg * rows_per_seg, i1 = min(h, i0 + rows_per_seg);
+      float lo[S][N], hi[S][N];
 #pragma unroll
-        for (int e = 0; e < N; ++e) acc[e] += wy[k] * t[e];
-      }
-      const long p = (long)row * w + j;
-      float xv[N];
-      VT<T>::load(x + p * C + cc * N, xv);
+      for (int k = 0; k < S; ++k) hrow(S * i0 - S / 2 + k, lo[k]);
+      for (int i = i0; i < i1; ++i) {
 #pragma unroll
-      for (int e = 0; e < N; ++e) {
-        const float gg = (xv[e] * sc[e] + sh[e] > 0.f) ? acc[e] : 0.f;
-        acc[e] = gg;
-        sg[e] += gg;
-        sgx[e] += gg * (xv[e] - mu[e]) * rs[e];
+        for (int k = 0; k < S; ++k) hrow(S * i - S / 2 + S + k, hi[k]);
+        const long p = ((long)b * h + i) * w + j;
+        float xv[N];
+        VT<T>::load(x + p * C + cc * N, xv);
+        float acc[N];
+#pragma unroll
+        for (int e = 0; e < N; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+          const float wyk = down_weight<S>(k, i, h);
+#pragma unroll
+          for (int e = 0; e < N; ++e) acc[e] += wyk * (k < S ? lo[k][e] : hi[k - S][e]);
+        }
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+          const float gg = (xv[e] * sc[e] + sh[e] > 0.f) ? acc[e] : 0.f;
+          acc[e] = gg;
+          sg[e] += gg;
+          sgx[e] += gg * (xv[e] - mu[e]) * rs[e];
+        }
+        VT<T>::store(g + p * C + cc * N, acc);
+#pragma unroll
+        for (int k = 0; k < S; ++k)
+#pragma unroll
+          for (int e = 0; e < N; ++e) lo[k][e] = hi[k][e];
       }
-      VT<T>::store(g + p * C + cc * N, acc);
     }
   }
 #pragma unroll
@@ -454,7 +484,6 @@ __global__ __launch_bounds__(256) void bn_relu_up_bwd_s_kernel(const T* __restri
   }
 }
 
-// pass 2: dx = gamma * rstd * (g - sum_g/n - xhat * sum_gx/n)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -1067,15 +1096,20 @@ S4F_API int s4f_bn_relu_up_fwd(const void* x, const float* scale, const float* s
   S4F_CHECK(x && scale && shift && y && B > 0 && h > 0 && w > 0 && s >= 1, "s4f_bn_relu_up_fwd: bad args");
   CH_CHECK("s4f_bn_relu_up_fwd");
   if (s == 2 || s == 4) {
-    const int rows = B * h;
-    const int grid = rows < 4096 ? rows : 4096;
+    const int ppb = 256 / (C / (dtype == S4F_BF16 ? 8 : 4));
+    const int nstrip = ceil_div(w, ppb);
+    int nseg = ceil_div(1024, B * nstrip);             // ~1024 blocks; a segment re-reads two rows at its top
+    if (nseg < 1) nseg = 1;
+    if (nseg > ceil_div(h, 4)) nseg = ceil_div(h, 4);
+    const int rows_per_seg = ceil_div(h, nseg);
+    const int grid = B * ceil_div(h, rows_per_seg) * nstrip;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S4F_BF16) {
-      if (s == 2) hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, B, h, w, C);
-      else hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, B, h, w, C);
+      if (s == 2) hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<bf16_t, 2>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, B, h, w, C, rows_per_seg);
+      else hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<bf16_t, 4>), dim3(grid), dim3(256), 0, st, (const bf16_t*)x, scale, shift, (bf16_t*)y, B, h, w, C, rows_per_seg);
     } else {
-      if (s == 2) hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<float, 2>), dim3(grid), dim3(256), 0, st, (const float*)x, scale, shift, (float*)y, B, h, w, C);
-      else hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<float, 4>), dim3(grid), dim3(256), 0, st, (const float*)x, scale, shift, (float*)y, B, h, w, C);
+      if (s == 2) hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<float, 2>), dim3(grid), dim3(256), 0, st, (const float*)x, scale, shift, (float*)y, B, h, w, C, rows_per_seg);
+      else hipLaunchKernelGGL((bn_relu_up_fwd_s_kernel<float, 4>), dim3(grid), dim3(256), 0, st, (const float*)x, scale, shift, (float*)y, B, h, w, C, rows_per_seg);
     }
     S4F_LAUNCH_CHECK();
     return 0;
@@ -1100,15 +1134,19 @@ S4F_API int s4f_bn_relu_up_bwd(const void* dy, const void* x, const float* scale
   int grid = grid_for(npix, rl * 4);
   const size_t shm = (size_t)rl * 2 * C * sizeof(float);
   if (s == 2 || s == 4) {
-    const int rows = B * h;
-    const int g2 = rows < 512 ? rows : 512;
+    const int nstrip = ceil_div(w, rl);
+    int nseg = ceil_div(1024, B * nstrip);             // ~1024 blocks; a segment re-reads S high-res rows at its top
+    if (nseg < 1) nseg = 1;
+    if (nseg > ceil_div(h, 4)) nseg = ceil_div(h, 4);
+    const int rows_per_seg = ceil_div(h, nseg);
+    const int g2 = B * ceil_div(h, rows_per_seg) * nstrip;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == S4F_BF16) {
-      if (s == 2) hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<bf16_t, 2>), dim3(g2), dim3(256), shm, st, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, rstd, (bf16_t*)g, sums, B, h, w, C);
-      else hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<bf16_t, 4>), dim3(g2), dim3(256), shm, st, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, rstd, (bf16_t*)g, sums, B, h, w, C);
+      if (s == 2) hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<bf16_t, 2>), dim3(g2), dim3(256), shm, st, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, rstd, (bf16_t*)g, sums, B, h, w, C, rows_per_seg);
+      else hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<bf16_t, 4>), dim3(g2), dim3(256), shm, st, (const bf16_t*)dy, (const bf16_t*)x, scale, shift, mean, rstd, (bf16_t*)g, sums, B, h, w, C, rows_per_seg);
     } else {
-      if (s == 2) hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<float, 2>), dim3(g2), dim3(256), shm, st, (const float*)dy, (const float*)x, scale, shift, mean, rstd, (float*)g, sums, B, h, w, C);
-      else hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<float, 4>), dim3(g2), dim3(256), shm, st, (const float*)dy, (const float*)x, scale, shift, mean, rstd, (float*)g, sums, B, h, w, C);
+      if (s == 2) hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<float, 2>), dim3(g2), dim3(256), shm, st, (const float*)dy, (const float*)x, scale, shift, mean, rstd, (float*)g, sums, B, h, w, C, rows_per_seg);
+      else hipLaunchKernelGGL((bn_relu_up_bwd_s_kernel<float, 4>), dim3(g2), dim3(256), shm, st, (const float*)dy, (const float*)x, scale, shift, mean, rstd, (float*)g, sums, B, h, w, C, rows_per_seg);
     }
     S4F_LAUNCH_CHECK();
     return 0;
