@@ -166,14 +166,17 @@ int s4f_bn_finalize(const float* sums, double count, const float* gamma, const f
 int s4f_bn_relu_up_fwd(const void* x, const float* scale, const float* shift, void* y, int B, int h, int w, int C,
                        int s, int dtype, s4f_stream stream);
 /* g = up_s^T(dy) * (x*scale+shift > 0); g T [B,h,w,C]; sums[0:C] += sum g, sums[C:2C] += sum g * xhat,
- * xhat = (x - mean) * rstd. */
+ * xhat = (x - mean) * rstd.  s = 1: g may be NULL (statistics only; s4f_bn_bwd_apply then re-masks dy itself). */
 int s4f_bn_relu_up_bwd(const void* dy, const void* x, const float* scale, const float* shift, const float* mean,
                        const float* rstd, void* g, float* sums, int B, int h, int w, int C, int s, int dtype,
                        s4f_stream stream);
 /* dx = gamma * rstd * (g - sum_g/count - xhat * sum_gx/count); dgamma += sum_gx; dbeta += sum_g (local sums:
- * pass the rank-local sums in sums_local for the parameter gradients, the all-reduced ones in sums). */
+ * pass the rank-local sums in sums_local for the parameter gradients, the all-reduced ones in sums).
+ * relu_scale / relu_shift non-NULL: `g` is the UNMASKED upstream gradient of a stage without upsampling and the ReLU mask
+ * (x*scale+shift > 0) is re-applied here - the masked copy is never written (one 2-byte/element pass less each way). */
 int s4f_bn_bwd_apply(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma,
-                     const float* sums, double count, void* dx, int64_t rows, int C, int dtype, s4f_stream stream);
+                     const float* sums, double count, void* dx, int64_t rows, int C, int dtype,
+                     const float* relu_scale, const float* relu_shift, s4f_stream stream);
 int s4f_bn_param_grads(const float* sums_local, float* dgamma, float* dbeta, int C, s4f_stream stream);
 
 /* ------------------------------------------------------------------------------------------- losses

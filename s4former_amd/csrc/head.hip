@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_s1_kernel(const T* __restrict
           sg[e] += gg;
           sgx[e] += gg * (xv[u][e] - mu[e]) * rs[e];
         }
-        VT<T>::store(g + p * C + cc * N, dv[u]);
+        if (g) VT<T>::store(g + p * C + cc * N, dv[u]);
       }
     }
   }
@@ -488,7 +488,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, const float* __restrict__ sums,
-                                                           float inv_count, T* __restrict__ dx, long rows, int C) {
+                                                           float inv_count, T* __restrict__ dx, long rows, int C,
+                                                           const float* __restrict__ rscale, const float* __restrict__ rshift) {
   constexpr int N = VT<T>::N;
   const int CPR = C / N;
   const long total = rows * CPR;
@@ -508,6 +509,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     a3[e] = -k * rstd[c] * sums[C + c] * inv_count;   // (x - mean)
   }
   const bool hoist = (stride % CPR) == 0;
+  float rsc[N], rsh[N];                              // optional ReLU re-masking of an unmasked upstream gradient
+#pragma unroll
+  for (int e = 0; e < N; ++e) { rsc[e] = rscale ? rscale[cc * N + e] : 0.f; rsh[e] = rscale ? rshift[cc * N + e] : 1.f; }
   for (long i = i0; i < total; i += 2 * stride) {
     float gv[2][N], xv[2][N], o[N];
     const bool two = i + stride < total;
@@ -521,6 +525,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     for (int u = 0; u < 2; ++u) {
       if (u == 1 && !two) break;
       const long ii = i + u * stride;
+      if (rscale) {
+        if (hoist) {
+#pragma unroll
+          for (int e = 0; e < N; ++e) gv[u][e] = (xv[u][e] * rsc[e] + rsh[e] > 0.f) ? gv[u][e] : 0.f;
+        } else {
+          const int c0 = (int)(ii % CPR) * N;
+#pragma unroll
+          for (int e = 0; e < N; ++e) gv[u][e] = (xv[u][e] * rscale[c0 + e] + rshift[c0 + e] > 0.f) ? gv[u][e] : 0.f;
+        }
+      }
       if (hoist) {
 #pragma unroll
         for (int e = 0; e < N; ++e) o[e] = a1[e] * gv[u][e] + a2[e] + a3[e] * (xv[u][e] - mu[e]);
@@ -1126,7 +1140,7 @@ S4F_API int s4f_bn_relu_up_bwd(const void* dy, const void* x, const float* scale
                                const float* rstd, void* g, float* sums, int B, int h, int w, int C, int s, int dtype,
                                s4f_stream stream) {
   DT_CHECK("s4f_bn_relu_up_bwd");
-  S4F_CHECK(dy && x && scale && shift && mean && rstd && g && sums && B > 0 && h > 0 && w > 0 && s >= 1, "s4f_bn_relu_up_bwd: bad args");
+  S4F_CHECK(dy && x && scale && shift && mean && rstd && (g || s == 1) && sums && B > 0 && h > 0 && w > 0 && s >= 1, "s4f_bn_relu_up_bwd: bad args");
   CH_CHECK("s4f_bn_relu_up_bwd");
   const int cpr = C / (dtype == S4F_BF16 ? 8 : 4);
   const int rl = 256 / cpr;
@@ -1166,15 +1180,17 @@ S4F_API int s4f_bn_relu_up_bwd(const void* dy, const void* x, const float* scale
 }
 
 S4F_API int s4f_bn_bwd_apply(const void* g, const void* x, const float* mean, const float* rstd, const float* gamma,
-                             const float* sums, double count, void* dx, int64_t rows, int C, int dtype, s4f_stream stream) {
+                             const float* sums, double count, void* dx, int64_t rows, int C, int dtype,
+                             const float* relu_scale, const float* relu_shift, s4f_stream stream) {
   DT_CHECK("s4f_bn_bwd_apply");
   S4F_CHECK(g && x && mean && rstd && gamma && sums && dx && rows > 0 && count > 0, "s4f_bn_bwd_apply: bad args");
   CH_CHECK("s4f_bn_bwd_apply");
   const long total = rows * (C / (dtype == S4F_BF16 ? 8 : 4));
   const int grid = grid_for(total, 256);
   const float inv = (float)(1.0 / count);
-  if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)x, mean, rstd, gamma, sums, inv, (bf16_t*)dx, (long)rows, C);
-  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)x, mean, rstd, gamma, sums, inv, (float*)dx, (long)rows, C);
+  S4F_CHECK((relu_scale == nullptr) == (relu_shift == nullptr), "s4f_bn_bwd_apply: relu_scale and relu_shift go together");
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)x, mean, rstd, gamma, sums, inv, (bf16_t*)dx, (long)rows, C, relu_scale, relu_shift);
+  else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)x, mean, rstd, gamma, sums, inv, (float*)dx, (long)rows, C, relu_scale, relu_shift);
   S4F_LAUNCH_CHECK();
   return 0;
 }

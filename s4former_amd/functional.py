@@ -19,6 +19,7 @@ from torch.autograd import Function
 from . import kernels as K
 from ._lib import BF16, F32, S4FError
 
+SKIP_MASKED_COPY = os.environ.get('S4F_SKIP_MASKED_COPY', '1') != '0'     # A/B switch of head_backward's s = 1 stages
 LOGIT_LD = 32   # channel stride of the low-resolution logits buffers (>= num_classes, multiple of 8)
 
 # ---------------------------------------------------------------------------------------------- side stream
@@ -450,14 +451,22 @@ def head_backward(dlo, dlo_t, sv, hp, store):
         cv, st = hp['convs'][k], sv['stages'][k]
         Cc, h, w, s, cin_k = st['Cc'], st['h'], st['w'], st['s'], st['cin']
         Mk = Bn * h * w
-        g = torch.empty(Mk, Cc, device=dev, dtype=T)
         bsums = zeros_small(2 * Cc, dev)
-        K.bn_relu_up_bwd(dcur, st['y'], st['scale'], st['shift'], st['mean'], st['rstd'], g, bsums, Bn, h, w, Cc, s, code)
+        dy = torch.empty(Mk, Cc, device=dev, dtype=T)
+        if s == 1 and SKIP_MASKED_COPY:
+            # no upsample: the masked gradient g = dcur * relu' is not materialised; the statistics pass and the apply pass
+            # both read (dcur, y) and re-mask on the fly
+            K.bn_relu_up_bwd(dcur, st['y'], st['scale'], st['shift'], st['mean'], st['rstd'], None, bsums, Bn, h, w, Cc, 1, code)
+            g, rs, rb = dcur, st['scale'], st['shift']
+        else:
+            g = torch.empty(Mk, Cc, device=dev, dtype=T)
+            K.bn_relu_up_bwd(dcur, st['y'], st['scale'], st['shift'], st['mean'], st['rstd'], g, bsums, Bn, h, w, Cc, s, code)
+            rs = rb = None
         K.bn_param_grads(bsums, store.grad_phys(cv['bn_w']), store.grad_phys(cv['bn_b']), Cc)
         if world > 1:
             dist.all_reduce(bsums)
-        dy = torch.empty(Mk, Cc, device=dev, dtype=T)
-        K.bn_bwd_apply(g, st['y'], st['mean'], st['rstd'], store.phys(cv['bn_w']), bsums, st['count'], dy, Mk, Cc, code)
+        K.bn_bwd_apply(g, st['y'], st['mean'], st['rstd'], store.phys(cv['bn_w']), bsums, st['count'], dy, Mk, Cc, code,
+                       relu_scale=rs, relu_shift=rb)
         del g
         st['y'] = None
         # conv weight gradient [Cc][3][3][cin] += dy^T (shifted inp)

@@ -411,24 +411,33 @@ def bn_relu_up_fwd(x, scale, shift, y, B, h, w, C, s, dtype):
 
 
 def bn_relu_up_bwd(dy, x, scale, shift, mean, rstd, g, sums, B, h, w, C, s, dtype):
+    """g None (s = 1 only): statistics pass without the masked copy"""
     _chk_dtype(dy, dtype, 'bn_relu_up_bwd dy'); _chk_dtype(x, dtype, 'bn_relu_up_bwd x'); _chk_dtype(g, dtype, 'bn_relu_up_bwd g')
     for t in (scale, shift, mean, rstd):
         _chk_f32(t, 'bn_relu_up_bwd'); _need(t, C, 'bn_relu_up_bwd')
     _chk_f32(sums, 'bn_relu_up_bwd sums'); _need(sums, 2 * C, 'bn_relu_up_bwd sums')
     _need(dy, B * h * s * w * s * C, 'bn_relu_up_bwd dy'); _need(x, B * h * w * C, 'bn_relu_up_bwd x')
-    _need(g, B * h * w * C, 'bn_relu_up_bwd g')
+    if g is None and s != 1:
+        raise S4FError('bn_relu_up_bwd: the statistics-only form exists for s = 1')
+    _need(g, B * h * w * C if g is not None else 0, 'bn_relu_up_bwd g')
     call('s4f_bn_relu_up_bwd', p(dy), p(x), p(scale), p(shift), p(mean), p(rstd), p(g), p(sums), B, h, w, C, s, dtype,
          stream())
 
 
-def bn_bwd_apply(g, x, mean, rstd, gamma, sums, count, dx, rows, C, dtype):
+def bn_bwd_apply(g, x, mean, rstd, gamma, sums, count, dx, rows, C, dtype, relu_scale=None, relu_shift=None):
+    """relu_scale / relu_shift given: g is the unmasked upstream gradient of an s = 1 stage, re-masked here"""
     _chk_dtype(g, dtype, 'bn_bwd_apply g'); _chk_dtype(x, dtype, 'bn_bwd_apply x'); _chk_dtype(dx, dtype, 'bn_bwd_apply dx')
     for t in (mean, rstd, gamma):
         _chk_f32(t, 'bn_bwd_apply'); _need(t, C, 'bn_bwd_apply')
     _chk_f32(sums, 'bn_bwd_apply sums'); _need(sums, 2 * C, 'bn_bwd_apply sums')
+    if (relu_scale is None) != (relu_shift is None):
+        raise S4FError('bn_bwd_apply: relu_scale and relu_shift go together')
+    for t in (relu_scale, relu_shift):
+        _chk_f32(t, 'bn_bwd_apply relu'); _need(t, C if t is not None else 0, 'bn_bwd_apply relu')
     for t in (g, x, dx):
         _need(t, rows * C, 'bn_bwd_apply')
-    call('s4f_bn_bwd_apply', p(g), p(x), p(mean), p(rstd), p(gamma), p(sums), float(count), p(dx), rows, C, dtype, stream())
+    call('s4f_bn_bwd_apply', p(g), p(x), p(mean), p(rstd), p(gamma), p(sums), float(count), p(dx), rows, C, dtype,
+         p(relu_scale), p(relu_shift), stream())
 
 
 def bn_param_grads(sums_local, dgamma, dbeta, C):

@@ -327,6 +327,15 @@ def test_bn_relu_up(K, code, s):
     check(dx, to_nhwc(xr.grad), code, 'bn+relu+up dx', tol=2e-4 if code == 0 else 3e-2)
     check(dgam, g_.grad, code, 'bn dgamma', tol=2e-4 if code == 0 else 3e-2)
     check(dbet, b_.grad, code, 'bn dbeta', tol=2e-4 if code == 0 else 3e-2)
+    if s == 1:
+        # statistics-only backward + re-masking apply (the masked gradient is never written): same sums, same dx
+        bsums2 = torch.zeros(2 * C, device='cuda')
+        dyd = dev(to_nhwc(dy), code)
+        K.bn_relu_up_bwd(dyd, xh, scale, shift, mean, rstd, None, bsums2, B, h, w, C, 1, code)
+        assert torch.allclose(bsums2, bsums, rtol=1e-5, atol=1e-5)
+        dx2 = torch.empty_like(dx)
+        K.bn_bwd_apply(dyd, xh, mean, rstd, dev(gamma), bsums2, rows, dx2, rows, C, code, relu_scale=scale, relu_shift=shift)
+        check(dx2, to_nhwc(xr.grad), code, 'bn+relu dx (re-masked apply)', tol=2e-4 if code == 0 else 3e-2)
     # eval mode (teacher): running stats, no update
     K.bn_finalize(None, 0, dev(gamma), dev(beta), rmd, rvd, 0.1, 1e-5, False, scale, shift, mean, rstd, C)
     K.bn_relu_up_fwd(xh, scale, shift, yk, B, h, w, C, s, code)
