@@ -555,8 +555,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 __global__ void bn_param_grads_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  dbeta[c] += sums[c];
-  dgamma[c] += sums[C + c];
+  atomicAdd(dbeta + c, sums[c]);                  // (the two calls of a shared head may run on different streams)
+  atomicAdd(dgamma + c, sums[C + c]);
 }
 
 // ------------------------------------------------------------------------------------------ upsampled logits helpers
