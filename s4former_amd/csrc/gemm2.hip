@@ -171,9 +171,12 @@ struct Feeder {
         const int yy = py[u] + (ty - 1), xx = px[u] + (tx - 1);
         const bool v = kt < kend[u] && yy >= 0 && yy < cH && xx >= 0 && xx < cW;
         src = v ? base + ((((long)pb[u] * cH + yy) * cW + xx) * ld + c) * 2 : g_zero_page;
-        px[u] += BK;
-        while (px[u] >= cW) { px[u] -= cW; ++py[u]; }
-        while (py[u] >= cH) { py[u] -= cH; ++pb[u]; }
+        // next k-iteration: 64 pixels further, branch-free (a per-lane `while` is a divergent loop)
+        px[u] += BK % cW; py[u] += BK / cW;
+        const bool wrapx = px[u] >= cW;
+        px[u] -= wrapx ? cW : 0; py[u] += wrapx ? 1 : 0;
+        const bool wrapy = py[u] >= cH;
+        py[u] -= wrapy ? cH : 0; pb[u] += wrapy ? 1 : 0;
       } else {
         src = (kt < kend[u] && ok[u]) ? cur[u] : g_zero_page;
         cur[u] += step;

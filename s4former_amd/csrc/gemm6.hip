@@ -35,6 +35,7 @@ struct KFeeder {
   int kk[4];                    // k-row of the slot inside the K-tile (0..63)
   int py[4], px[4];             // conv: image coordinates of the slot's pixel in the current K-tile of the part
   int dy, dx;                   // conv: tap offsets
+  int kdx, kdy;                 // conv: (x, y) advance of 64 pixels = BK % W, BK / W
   int wave;
 
   __device__ __forceinline__ int cb_of(int u) const {      // column block of slot u
@@ -50,6 +51,7 @@ struct KFeeder {
     ld = IS_A ? d.lda : d.ldb;
     const int lim = IS_A ? d.M : d.N;
     K = d.K; kt_end = kt_end_; cH = d.cH; cW = d.cW;
+    kdx = d.cW > 0 ? BK % d.cW : 0; kdy = d.cW > 0 ? BK / d.cW : 0;
     const int r = lane >> 3, pos = lane & 7;
     const int c = (((pos >> 1) ^ ((r >> 1) & 3)) << 1) | (pos & 1);          // source chunk of this lane
     long bytes;
@@ -96,10 +98,12 @@ struct KFeeder {
       bool ok = live && kk[u] < klim;
       if constexpr (MODE == S4F_OP_K_CONV) {
         const int yy = py[u] + dy, xx = px[u] + dx;
-        ok = ok && yy >= 0 && yy < cH && xx >= 0 && xx < cW;
-        px[u] += BK;
-        while (px[u] >= cW) { px[u] -= cW; ++py[u]; }
-        while (py[u] >= cH) py[u] -= cH;
+        ok = ok && (unsigned)yy < (unsigned)cH && (unsigned)xx < (unsigned)cW;
+        // next K-tile: 64 pixels further, branch-free (a per-lane `while` is a divergent loop in every load segment)
+        px[u] += kdx; py[u] += kdy;
+        const bool wrapx = px[u] >= cW;
+        px[u] -= wrapx ? cW : 0; py[u] += wrapx ? 1 : 0;
+        py[u] -= py[u] >= cH ? cH : 0;
       }
       bufl16(rsrc, ok ? voff[u] : G6_OOB, so, img + cb_of(u) * 8192 + kgrp_of(u) * 1024);
     }
