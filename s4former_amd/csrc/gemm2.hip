@@ -84,6 +84,7 @@ struct Feeder {
   int py[NSLOT], px[NSLOT], pb[NSLOT];
   int srcchunk[NSLOT], krow[NSLOT];
   int wave, lane;
+  int tleft;                  // conv modes: k-iterations until the next tap change
 
   // (re)compute the slot pointers for k-iteration kt (full recompute; used at start and on tap changes)
   __device__ __forceinline__ void seek(int kt) {
@@ -151,11 +152,20 @@ struct Feeder {
       }
     }
     seek(kt0);
+    if constexpr (MODE == S4F_OP_ROW_CONV || MODE == S4F_OP_K_TAPSPLIT) {
+      const int tpt = cC / BK;
+      tleft = tpt - (kt0 % tpt) + 1;                 // the first issue(kt0) must not re-seek
+    }
   }
 
   __device__ __forceinline__ void issue(int kt, char* img) {
     if constexpr (MODE == S4F_OP_ROW_CONV || MODE == S4F_OP_K_TAPSPLIT) {
-      if ((kt * BK) % cC == 0) seek(kt);             // wave-uniform: tap changed
+      // wave-uniform tap change every cC / 64 k-iterations (issue() is called for consecutive kt): a countdown instead
+      // of an integer modulo per call
+      if (--tleft == 0) {
+        tleft = cC / BK;
+        seek(kt);
+      }
     }
 #pragma unroll
     for (int u = 0; u < NSLOT; ++u) {

@@ -53,6 +53,7 @@ struct PFeeder {
   int pyx[4], pb[4];            // conv: (y << 16 | x), image index of the slot's pixel
   int chunk;                    // source 16-B chunk of this lane inside the 128-B k-row (swizzle applied)
   int soff[2];                  // conv: scalar byte offset of the part's current tap is folded into voff; this is the k base
+  int tpt, tleft[2];            // conv: K-tiles per tap; K-tiles until the part's next tap change
   int wave;
 
   // 8-row block of slot u: A parts are rows {0-63, 128-191} / {64-127, 192-255}; B parts are the low / high 32 columns
@@ -108,13 +109,22 @@ struct PFeeder {
     }
     seek<0>(kt0);
     seek<1>(kt0);
+    if constexpr (MODE == S4F_OP_ROW_CONV) {
+      tpt = cC / BK;
+      // issue(kt) is called once per K-tile and part in ascending order starting at kt0: the first call must not re-seek
+      tleft[0] = tleft[1] = tpt - (kt0 % tpt) + 1;
+    }
   }
 
   // two DMA instructions: part PART of K-tile kt into the image at img
   template <int PART>
   __device__ __forceinline__ void issue(int kt, char* img) {
     if constexpr (MODE == S4F_OP_ROW_CONV) {
-      if ((kt * BK) % cC == 0 && kt < kt_end) seek<PART>(kt);       // wave-uniform: tap changed
+      // wave-uniform tap change every cC / 64 K-tiles: a countdown per part instead of an integer modulo per issue
+      if (--tleft[PART] == 0) {
+        tleft[PART] = tpt;
+        if (kt < kt_end) seek<PART>(kt);
+      }
     }
     const bool live = kt < kt_end;                   // scalar
     const int so = kt * (BK * 2) - (MODE == S4F_OP_ROW_CONV ? soff[PART] : 0);
