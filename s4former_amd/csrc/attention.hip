@@ -225,23 +225,39 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
           }
     }
     constexpr float kc = HAS_BIAS ? 1.f : kScale2;      // units of m / st relative to log2 units
-    float alpha[2];
+    // bf16 mode: the running maximum is kept while the new one exceeds it by < 2^kDefer (P stays <= 2^kDefer, harmless for
+    // the fp32 accumulators and bf16 P operands).  The test is done on the LANE-LOCAL maxima first: only if some lane of
+    // the wave sees such a jump (wave vote) are the maxima reduced across the four lanes of a query (two dependent
+    // cross-lane shuffles per query tile) - after the first tiles that is rare.  fp32 parity mode: exact running maximum.
+    constexpr float kDefer = sizeof(T) == 2 ? 6.0f : 0.0f;
+    float alpha[2] = {1.f, 1.f};
+    float mxl[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       float mx = fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), fmaxf(st[0][qt][2], st[0][qt][3]));
 #pragma unroll
       for (int ks = 1; ks < 4; ++ks)
         mx = fmaxf(mx, fmaxf(fmaxf(st[ks][qt][0], st[ks][qt][1]), fmaxf(st[ks][qt][2], st[ks][qt][3])));
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // bf16 mode: keep the old maximum while the new one exceeds it by < 2^kDefer (P stays <= 2^kDefer, harmless for
-      // the fp32 accumulators and bf16 P operands); the O / l rescale then happens only when the maximum really moves.
-      // fp32 parity mode: exact running maximum.
-      constexpr float kDefer = sizeof(T) == 2 ? 6.0f : 0.0f;
-      float mnew = fmaxf(m[qt], mx);                // finite: every tile has >= 1 valid key
-      if (kDefer > 0.f && (mnew - m[qt]) * kc <= kDefer) mnew = m[qt];
-      alpha[qt] = fexp2<T>((m[qt] - mnew) * kc);    // m = -inf on the first tile -> 0
-      const float mc = -mnew * kc;
+      mxl[qt] = mx;
+    }
+    const bool jump = !((mxl[0] - m[0]) * kc <= kDefer) || !((mxl[1] - m[1]) * kc <= kDefer);   // (m = -inf: true)
+    if (__any(jump)) {
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = mxl[qt];
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float mnew = fmaxf(m[qt], mx);                // finite: every tile has >= 1 valid key
+        if (kDefer > 0.f && (mnew - m[qt]) * kc <= kDefer) mnew = m[qt];
+        alpha[qt] = fexp2<T>((m[qt] - mnew) * kc);    // m = -inf on the first tile -> 0
+        m[qt] = mnew;
+      }
+    }
+    // the row sums stay lane-partial (each of a query's four lanes sums its own 16 keys of every tile; same alpha in all
+    // four): they are reduced across lanes once, after the last tile
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+      const float mc = -m[qt] * kc;
       float ps = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
@@ -251,10 +267,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
           st[ks][qt][r] = p;
           ps += p;
         }
-      ps += __shfl_xor(ps, 16, 64);
-      ps += __shfl_xor(ps, 32, 64);
       lsum[qt] = lsum[qt] * alpha[qt] + ps;
-      m[qt] = mnew;
     }
     // rescale O only when some query of this wave moved its maximum (wave-uniform branch)
     if (!__all(alpha[0] == 1.f && alpha[1] == 1.f)) {
@@ -288,6 +301,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
   T* cb = reinterpret_cast<T*>(a.ctx) + (long)b * N * (H * 64) + h * 64;
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
+    lsum[qt] += __shfl_xor(lsum[qt], 16, 64);        // lane-partial row sums -> row sums
+    lsum[qt] += __shfl_xor(lsum[qt], 32, 64);
     const float il = 1.f / lsum[qt];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
