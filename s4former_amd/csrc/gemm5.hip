@@ -83,7 +83,7 @@ struct PFeeder {
   }
 
   __device__ __forceinline__ void init(const s4f_gemm_desc& d, int blk0, int kt0, int kt_end_) {
-    wave = threadIdx.x >> 6;
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: LDS-DMA bases (M0) without per-issue readfirstlane
     const int lane = threadIdx.x & 63;
     const void* basep = IS_A ? d.A : d.B;
     ld = IS_A ? d.lda : d.ldb;
@@ -144,7 +144,7 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
   int kt_end = kt_beg + args.nk_per_split;
   if (kt_end > args.nk) kt_end = args.nk;
 
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: LDS-DMA bases (M0) without per-issue readfirstlane
   const int wr = wave >> 2, wc = wave & 3;
   const int l = threadIdx.x & 63, g = l >> 4, li = l & 15;
 
