@@ -318,31 +318,6 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
   }
 }
 
-// ------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
-template <typename T>
-__global__ void attn_delta_kernel(const T* ctx, const T* dctx, float* delta, int B, int N, int H) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, q, h)
-  const long total = (long)B * N * H;
-  if (idx >= total) return;
-  const int h = idx % H;
-  const long bq = idx / H;
-  const int q = bq % N;
-  const int b = bq / N;
-  const T* o = ctx + bq * (H * 64) + h * 64;
-  const T* d = dctx + bq * (H * 64) + h * 64;
-  float s = 0.f;
-  constexpr int EPC = 16 / sizeof(T);
-#pragma unroll
-  for (int i = 0; i < 64 / EPC; ++i) {
-    const chunk16 co = ld_global16(o + i * EPC), cd = ld_global16(d + i * EPC);
-    const T* po = reinterpret_cast<const T*>(&co);
-    const T* pd = reinterpret_cast<const T*>(&cd);
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) s += to_f32<T>(po[e]) * to_f32<T>(pd[e]);
-  }
-  delta[((long)b * H + h) * N + q] = s;
-}
-
 // ------------------------------------------------------------------------------------------ dQ
 template <typename T, int NW, bool HAS_BIAS>
 __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
@@ -361,20 +336,31 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
   const T* dob = reinterpret_cast<const T*>(a.dctx) + (long)b * N * ldc + h * 64;
   const int q0 = blockIdx.x * 32 * NW + wave * 32;
 
+  // delta = rowsum(dO * O) of this wave's queries is computed here (each (b, h, query) belongs to exactly one wave of
+  // this grid) and stored for the dK/dV kernel that follows on the stream: no separate delta pass over ctx / dctx
+  const T* ob = reinterpret_cast<const T*>(a.ctx) + (long)b * N * ldc + h * 64;
   Frag<T> fq[2][2], fdo[2][2];
   float flagq[2], lse2[2], delq[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
     const int q = q0 + qt * 16 + li;
     const bool v = q < N;
+    float dsum = 0.f;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       gload_frag<T>(fq[qt][s], qb + (long)q * ld + s * 32 + 8 * g, v);
       gload_frag<T>(fdo[qt][s], dob + (long)q * ldc + s * 32 + 8 * g, v);
+      Frag<T> fo;
+      gload_frag<T>(fo, ob + (long)q * ldc + s * 32 + 8 * g, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dsum += to_f32<T>(fdo[qt][s].v[j]) * to_f32<T>(fo.v[j]);
     }
+    dsum += __shfl_xor(dsum, 16, 64);               // the four lanes of a query hold 16 of its 64 head dims each
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (g == 0 && v) a.delta[((long)b * H + h) * N + q] = dsum;
     flagq[qt] = (HAS_BIAS && a.row_flag && v) ? a.row_flag[(long)b * N + q] : 1.f;
     lse2[qt] = v ? a.lse[((long)b * H + h) * N + q] * kLog2e : 0.f;
-    delq[qt] = v ? a.delta[((long)b * H + h) * N + q] : 0.f;
+    delq[qt] = dsum;
   }
   f32x4 dq[2][4];
 #pragma unroll
@@ -669,9 +655,6 @@ int fwd_launch(const AttnArgs& a, hipStream_t st) {
 }
 template <typename T, int NW>
 int bwd_launch(const AttnArgs& a, hipStream_t st) {
-  const long total = (long)a.B * a.N * a.H;
-  hipLaunchKernelGGL((attn_delta_kernel<T>), dim3(ceil_div(total, 256)), dim3(256), 0, st,
-                     reinterpret_cast<const T*>(a.ctx), reinterpret_cast<const T*>(a.dctx), a.delta, a.B, a.N, a.H);
   dim3 grid(ceil_div(a.N, 32 * NW), a.H, a.B);
   if (a.bias_u) {
     hipLaunchKernelGGL((attn_dq_kernel<T, NW, true>), grid, dim3(64 * NW), 0, st, a);
