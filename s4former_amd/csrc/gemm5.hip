@@ -317,6 +317,63 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
   const bool wide = (d.N % 8 == 0) && (n0 + 256 <= d.N) && (!d.atomic || (d.act == S4F_ACT_NONE && !d.out_t && !d.pos)) &&
                     (!d.out_t || d.ldo_t % 8 == 0) && (!d.out_pre || d.ldo_pre % 8 == 0) && (!d.aux || d.ld_aux % 8 == 0) &&
                     (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % 4 == 0);
+  // bf16 outputs (bias only: qkv, the input gradients, conv fwd / dgrad; GELU with its derivative: fc1; times a gelu'
+  // tensor: the fc2 input gradient): the tile is staged ONCE as bf16 by all eight waves together (135 KiB) and leaves in
+  // 16-byte rows - one barrier pair instead of two, half the LDS bytes of the fp32 staging.  The activations are applied
+  // in the read-out to the bf16-rounded pre-activation (one more rounding to 8 bits before an 8-bit output).
+  const bool plain_t = wide && d.out_t && !d.out_f32 && !d.resid && !d.pos && !d.atomic &&
+                       (d.act == S4F_ACT_NONE ? !d.out_pre : true);
+  if (plain_t) {
+    constexpr int LDB = 256 + 8;                     // staged row = 528 B
+    bf16_t* tb = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* out_t = reinterpret_cast<bf16_t*>(d.out_t);
+    bf16_t* out_pre = reinterpret_cast<bf16_t*>(d.out_pre);
+    const bf16_t* aux = reinterpret_cast<const bf16_t*>(d.aux);
+    static_for<4>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      const int col = wc * 64 + j * 16 + li;
+      const float bias = d.bias ? d.bias[n0 + col] : 0.f;
+      static_for<8>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tb[(wr * 128 + i * 16 + 4 * g + r) * LDB + col] = (bf16_t)(acc[i][j][r] * d.alpha + bias);
+      });
+      if constexpr (TAIL) {
+        if ((j >> 1) == wr) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tb[(256 + 4 * g + r) * LDB + col] = (bf16_t)(tacc[j & 1][r] * d.alpha + bias);
+        }
+      }
+    });
+    __syncthreads();
+    constexpr int NROWS = TAIL ? 256 + TAIL_MAX : 256;
+    const int act = d.act;
+#pragma unroll 4
+    for (int idx = threadIdx.x; idx < NROWS * 32; idx += 512) {
+      const int row = idx >> 5, cc = idx & 31;
+      const int m = m0 + row;
+      if (m >= d.M) continue;
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(tb + row * LDB + cc * 8);
+      const int n = n0 + cc * 8;
+      if (act == S4F_ACT_GELU) {
+        bf16x8 pv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float gy, gd;
+          gelu_pair<false>((float)v[e], gy, gd);
+          v[e] = (bf16_t)gy;
+          pv[e] = (bf16_t)gd;
+        }
+        if (out_pre) *reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n) = pv;
+      } else if (act == S4F_ACT_GELU_BWD) {
+        const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * (float)z[e]);
+      }
+      *reinterpret_cast<bf16x8*>(out_t + (long)m * d.ldo_t + n) = v;
+    }
+    return;
+  }
   if (wide) {
     constexpr int LDT = 256 + 4;
     float* tile = reinterpret_cast<float*>(smem);
