@@ -262,12 +262,12 @@ __device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, i
 #endif
 // One pass of the coalesced epilogue: 128 staged fp32 rows (tile, row stride BN + 4) -> global, 16 B per lane.
 // mrow0 = global row of staged row 0; rows >= M are skipped.
-template <int BN, int NW>
+template <int BN, int NW, int ROWS = 128>
 __device__ __forceinline__ void epilogue_rows(const s4f_gemm_desc& d, const float* tile, const int mrow0, const int n0,
                                               const bool first_split) {
   constexpr int LDT = BN + 4;
   constexpr int CPR = BN / 8;                    // 8-column chunks per row
-  constexpr int ITEMS = 128 * CPR / (64 * NW);   // chunk items per thread per pass
+  constexpr int ITEMS = ROWS * CPR / (64 * NW);  // chunk items per thread per pass
   bf16_t* out_t = reinterpret_cast<bf16_t*>(d.out_t);
   bf16_t* out_pre = reinterpret_cast<bf16_t*>(d.out_pre);
   const bf16_t* aux = reinterpret_cast<const bf16_t*>(d.aux);
@@ -275,7 +275,7 @@ __device__ __forceinline__ void epilogue_rows(const s4f_gemm_desc& d, const floa
     {
       if (d.atomic) {
         // split-K partial sums: fp32 atomics, each wave-instruction covers 64 consecutive columns (256 B) of one row
-        constexpr int AITEMS = 128 * BN / (64 * NW);
+        constexpr int AITEMS = ROWS * BN / (64 * NW);
 #pragma unroll 4
         for (int it = 0; it < AITEMS; ++it) {
           const int idx = threadIdx.x + it * 64 * NW;

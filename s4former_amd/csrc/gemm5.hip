@@ -375,28 +375,34 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
     return;
   }
   if (wide) {
+    // fp32 staging (residual / fp32 / atomic outputs): two passes of 128 staged rows; in pass p EVERY wave stages rows
+    // 64 p .. 64 p + 63 of its 128-row half (staged rows 0-63: upper half of the tile, 64-127: lower half)
     constexpr int LDT = 256 + 4;
     float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int pass = 0; pass < (TAIL ? 3 : 2); ++pass) {
+    for (int pass = 0; pass < 2; ++pass) {
       __syncthreads();
-      if (pass == 2) {
+      static_for<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<4>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) tile[(4 * g + r) * LDT + wc * 64 + wr * 32 + j * 16 + li] = tacc[j][r];
-      } else if (wr == pass) {
-        static_for<8>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          static_for<4>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tile[(i * 16 + 4 * g + r) * LDT + wc * 64 + j * 16 + li] = acc[i][j][r];
-          });
+          for (int r = 0; r < 4; ++r)
+            tile[(wr * 64 + i * 16 + 4 * g + r) * LDT + wc * 64 + j * 16 + li] = pass == 0 ? acc[i][j][r] : acc[4 + i][j][r];
         });
-      }
+      });
       __syncthreads();
-      epilogue_rows<256, 8>(d, tile, m0 + pass * 128, n0, first_split);
+      epilogue_rows<256, 8, 64>(d, tile, m0 + pass * 64, n0, first_split);
+      epilogue_rows<256, 8, 64>(d, tile + 64 * LDT, m0 + 128 + pass * 64, n0, first_split);
+    }
+    if constexpr (TAIL) {
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tile[(4 * g + r) * LDT + wc * 64 + wr * 32 + j * 16 + li] = tacc[j][r];
+      __syncthreads();
+      epilogue_rows<256, 8, 64>(d, tile, m0 + 256, n0, first_split);
     }
     return;
   }

@@ -36,3 +36,14 @@ for h in (4, 10, 4, 10):
     gb = timeit(lambda: K.gemm(x, w, M, N, Kd, Kd, Kd, 1, out_t=y, ldo_t=N, aux=aux, ld_aux=N, act=K.ACT_GELU_BWD, tile_hint=h))
     p = timeit(lambda: K.gemm(x, w, M, N, Kd, Kd, Kd, 1, bias=b, out_t=y, ldo_t=N, tile_hint=h))
     print(f'hint {h}: GELU {g:6.1f} us   GELU_BWD {gb:6.1f} us   plain {p:6.1f} us', flush=True)
+
+# residual epilogue (proj / fc2 forward): fp32 residual in, fp32 out
+for (N2, K2) in ((768, 3072), (768, 768)):
+    x2 = torch.randn(M, K2, device='cuda').to(T)
+    w2 = (torch.randn(N2, K2, device='cuda') * 0.02).to(T)
+    r2 = torch.randn(M, N2, device='cuda')
+    o2 = torch.empty(M, N2, device='cuda')
+    b2 = torch.randn(N2, device='cuda')
+    for h in (8, 4, 10, 8, 4, 10):
+        t = timeit(lambda: K.gemm(x2, w2, M, N2, K2, K2, K2, 1, bias=b2, resid=r2, ldr=N2, out_f32=o2, ldo_f32=N2, tile_hint=h))
+        print(f'resid N={N2} K={K2} hint {h}: {t:6.1f} us', flush=True)
