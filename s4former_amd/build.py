@@ -20,10 +20,6 @@ BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibili
 FLAGS = BASE_FLAGS + ['-mllvm', '-amdgpu-mfma-vgpr-form=1']
 # per-file overrides: gemm4.hip keeps its 256 accumulators per lane in AGPRs (no vgpr-form); it #includes gemm2.hip
 FILE_FLAGS = {'gemm4.hip': BASE_FLAGS}
-if os.environ.get('S4F_EPI_NT'):
-    FLAGS = FLAGS + ['-DS4F_EPI_NT']
-    BASE_FLAGS = BASE_FLAGS + ['-DS4F_EPI_NT']
-    FILE_FLAGS = {'gemm4.hip': BASE_FLAGS}
 if os.environ.get('S4F_G5_PROBES'):
     FILE_FLAGS['gemm5.hip'] = FLAGS + ['-DG5_PROBES']
 FILE_DEPS = {'gemm4.hip': ['gemm2.hip'], 'gemm5.hip': ['gemm2.hip'], 'gemm6.hip': ['gemm2.hip']}

@@ -255,11 +255,8 @@ __device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, i
   }
 }
 
-#ifdef S4F_EPI_NT
-#define EPI_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
+// (non-temporal stores here were measured: no effect on the token GEMMs)
 #define EPI_STORE(ptr, val) (*(ptr) = (val))
-#endif
 // One pass of the coalesced epilogue: 128 staged fp32 rows (tile, row stride BN + 4) -> global, 16 B per lane.
 // mrow0 = global row of staged row 0; rows >= M are skipped.
 template <int BN, int NW, int ROWS = 128>
