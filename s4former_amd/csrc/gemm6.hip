@@ -273,24 +273,24 @@ __device__ __forceinline__ void g6_body(const GemmArgs& args, const int tm, cons
   const bool wide = (d.N % 8 == 0) && (n0 + 256 <= d.N) && !d.out_t && !d.pos && d.act == S4F_ACT_NONE &&
                     (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % 4 == 0);
   if (wide) {
+    // two passes of 128 staged fp32 rows; in pass p EVERY wave stages rows 64 p .. 64 p + 63 of its 128-row half
     constexpr int LDT = 256 + 4;
     float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       __syncthreads();
-      if (wr == pass) {
-        static_for<8>([&](auto ic) {
-          constexpr int i = decltype(ic)::value;
-          static_for<4>([&](auto jc) {
-            constexpr int j = decltype(jc)::value;
-            const int col = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + li;
+      static_for<4>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        static_for<4>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const int col = (j >> 1) * 128 + wc * 32 + (j & 1) * 16 + li;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) tile[(i * 16 + 4 * g + r) * LDT + col] = acc[i][j][r];
-          });
+          for (int r = 0; r < 4; ++r) tile[(wr * 64 + i * 16 + 4 * g + r) * LDT + col] = pass == 0 ? acc[i][j][r] : acc[4 + i][j][r];
         });
-      }
+      });
       __syncthreads();
-      epilogue_rows<256, 8>(d, tile, m0 + pass * 128, n0, first_split);
+      epilogue_rows<256, 8, 64>(d, tile, m0 + pass * 64, n0, first_split);
+      epilogue_rows<256, 8, 64>(d, tile + 64 * LDT, m0 + 128 + pass * 64, n0, first_split);
     }
     return;
   }
