@@ -927,6 +927,13 @@ __global__ __launch_bounds__(256) void upce_bwd_lse_kernel(const float* __restri
 #pragma unroll
     for (int n = 0; n < 3; ++n) P[m][n] = lo + (((long)b * h + rr[m]) * w + cc[n]) * ldc;
   const long p = ((long)b * h + i) * w + j;
+  // the nine neighbour chunks of class group c4 + 1 are in flight while group c4 is computed (the loop is not unrolled:
+  // without the prefetch every group pays a full global-load latency before its ~500 VALU instructions)
+  f32x4 Ln[3][3];
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int n = 0; n < 3; ++n) Ln[m][n] = *reinterpret_cast<const f32x4*>(P[m][n]);
 #pragma unroll 1
   for (int c4 = 0; c4 < kMaxC / 4; ++c4) {
     if (c4 * 4 >= ldc) break;
@@ -936,7 +943,13 @@ __global__ __launch_bounds__(256) void upce_bwd_lse_kernel(const float* __restri
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
-        for (int n = 0; n < 3; ++n) L[m][n] = *reinterpret_cast<const f32x4*>(P[m][n] + c4 * 4);
+        for (int n = 0; n < 3; ++n) L[m][n] = Ln[m][n];
+      if ((c4 + 1) * 4 < C) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+          for (int n = 0; n < 3; ++n) Ln[m][n] = *reinterpret_cast<const f32x4*>(P[m][n] + (c4 + 1) * 4);
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float xr[3][R];
