@@ -54,6 +54,11 @@ if which == 'ksweep':     # fixed (prologue + epilogue) vs per-K-tile cost: time
             row.append(f'h{h} {us:7.1f}us')
         print(f'nt M=16384 N=3072 K={Kd:5d} | ' + ' | '.join(row), flush=True)
     sys.exit(0)
+if which == 'h10':        # the ping-pong kernel on the token shapes (A/B of two builds: S4F_LIB=<other library>)
+    for (M, N, Kd) in ((16400, 3072, 768), (16400, 2304, 768), (16400, 768, 3072), (16400, 768, 768), (16384, 3072, 3072), (8200, 3072, 768)):
+        us = min(nt(M, N, Kd, 10) for _ in range(3))
+        print(f'nt M={M} N={N} K={Kd} h10 {us:8.1f}us {2.0 * M * N * Kd / us / 1e6:6.0f}TF', flush=True)
+    sys.exit(0)
 if which == 'big':
     for (M, N, Kd) in ((8192, 8192, 4096), (4096, 4096, 4096), (16384, 3072, 768)):
         print(f'nt M={M} N={N} K={Kd} | ' + ' | '.join(f'h{h} {nt(M, N, Kd, h):8.1f}us {2.0 * M * N * Kd / nt(M, N, Kd, h) / 1e6:6.0f}TF' for h in (3, 4, 10)), flush=True)
