@@ -66,3 +66,12 @@ for i in range(nsl):
             top = sorted(cell[q].items(), key=lambda kv: -kv[1])[:3]
             parts.append(f'{qname[q]}:{tot:4.2f} ' + ','.join(f'{f}{v:.1f}' for f, v in top))
     print(f'{i * dt:6.1f} ms | ' + ' | '.join(parts))
+
+# optional: list every kernel between two times (ms from step start): python tools/timeline_report.py db k dt t_from t_to
+if len(sys.argv) > 5:
+    a, b = t0 + float(sys.argv[4]) * 1e6, t0 + float(sys.argv[5]) * 1e6
+    print(f'--- kernels starting in [{sys.argv[4]}, {sys.argv[5]}] ms')
+    for n, s, e, st, q in R:
+        if a <= s < b:
+            nn = re.sub(r'\(anonymous namespace\)::', '', n).replace('void ', '')
+            print(f'{(s - t0) / 1e6:8.3f} +{(e - s) / 1e3:7.1f}us {qname[q]} {nn[:90]}')
