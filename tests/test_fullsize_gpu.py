@@ -1,4 +1,5 @@
-"""Full-size properties (BASELINE cfg3/4: DeiT-B 512x512, 8 + 8 images), where the oracle would take minutes per step:
+"""Full-size properties (BASELINE cfg3/4: DeiT-B 512x512, 8 + 8 images, 21 classes; cfg5: 768x768, 4 + 4 images, 19 classes,
+2305 tokens), where the oracle would take minutes per step:
 
 * the bf16 perf path (gemm2 / gemm5 / gemm6 variants picked by the shipped table at exactly the production shapes) agrees
   with the fp32 parity path (gemm.hip, exact fp32 MFMA chain) on the same weights and batch: every loss term, the
@@ -19,7 +20,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def _one_step(dtype, gain):
+def _one_step(dtype, gain, n_sup, n_unsup, img, ncls):
     import bench
     import s4former_amd as S
     from s4former_amd.functional import join_side_streams
@@ -27,18 +28,18 @@ def _one_step(dtype, gain):
     dev = torch.device('cuda', 0)
     S.set_compute_dtype(dtype)
     torch.manual_seed(1999)
-    model = S.build_segmentor(setr_pup_model(img=512, num_classes=21, unsup_weight=1.0, plain_mt_pseudo_loss=True))
+    model = S.build_segmentor(setr_pup_model(img=img, num_classes=ncls, unsup_weight=1.0, plain_mt_pseudo_loss=True))
     model.init_weights()
     model.train()
     model.to(dev)
     model.log_vars_as_tensors = True
     opt = S.build_optimizer(model, dict(OPTIMIZER))
     sched = S.PolyLR(opt, MAX_ITERS)
-    batch = synthetic_batch(1999, 8, 8, img=512, num_classes=21, device=dev)
+    batch = synthetic_batch(1999, n_sup, n_unsup, img=img, num_classes=ncls, device=dev)
     model.ensure_engine(dev)
     model.student_store.mark_dirty()
     if gain is None:
-        gain = bench.calibrate_teacher(model, batch, 8, 8, 0.5)
+        gain = bench.calibrate_teacher(model, batch, n_sup, n_unsup, 0.5)
     else:
         with torch.no_grad():
             model.decode_head_ema.conv_seg.weight.mul_(gain)
@@ -68,12 +69,12 @@ def _one_step(dtype, gain):
     return res
 
 
-@pytest.fixture(scope='module')
-def runs():
+@pytest.fixture(scope='module', params=[(8, 8, 512, 21), (4, 4, 768, 19)], ids=['cfg3_512', 'cfg5_768'])
+def runs(request):
     import s4former_amd as S
     try:
-        f32 = _one_step('fp32', None)
-        bf16 = _one_step('bf16', f32['gain'])
+        f32 = _one_step('fp32', None, *request.param)
+        bf16 = _one_step('bf16', f32['gain'], *request.param)
     finally:
         S.set_compute_dtype('fp32')
     return f32, bf16
