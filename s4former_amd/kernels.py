@@ -68,7 +68,8 @@ _TUNED_DISK = {}
 if _TUNE_FILE and os.path.exists(_TUNE_FILE):
     try:
         import json as _json
-        _TUNED_DISK = {k: tuple(v) for k, v in _json.load(open(_TUNE_FILE)).items()}
+        with open(_TUNE_FILE) as _f:
+            _TUNED_DISK = {k: tuple(v) for k, v in _json.load(_f).items()}
     except (OSError, ValueError):
         _TUNED_DISK = {}
 if os.environ.get('S4F_TUNE_SAVE'):
