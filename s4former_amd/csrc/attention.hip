@@ -78,6 +78,12 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr float kScale2 = 0.125f * kLog2e;       // (1/8) * log2(e): scores are kept in log2 units
 
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
 template <typename T> __device__ __forceinline__ float fexp2(float x);
 template <> __device__ __forceinline__ float fexp2<float>(float x) { return exp2f(x); }
 template <> __device__ __forceinline__ float fexp2<bf16_t>(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -208,10 +214,9 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const f32x4 uu = *reinterpret_cast<const f32x4*>(us + ks * 16 + 4 * g);
+        const f32x4 k4 = f32x4{kScale2, kScale2, kScale2, kScale2};
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int qt = 0; qt < 2; ++qt) st[ks][qt][r] = fmaf(st[ks][qt][r], kScale2, uu[r] * flagq[qt]);
+        for (int qt = 0; qt < 2; ++qt) st[ks][qt] = __builtin_elementwise_fma(st[ks][qt], k4, uu * flagq[qt]);   // packed fp32
       }
     }
     if (ragged) {
@@ -234,10 +239,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
     float mxl[2];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-      float mx = fmaxf(fmaxf(st[0][qt][0], st[0][qt][1]), fmaxf(st[0][qt][2], st[0][qt][3]));
+      // v_max3_f32 written out: fmaxf() makes the compiler canonicalise every MFMA result first (one extra v_max each)
+      float mx = max3f(st[0][qt][0], st[0][qt][1], st[0][qt][2]);
+      mx = max3f(mx, st[0][qt][3], st[1][qt][0]);
 #pragma unroll
-      for (int ks = 1; ks < 4; ++ks)
-        mx = fmaxf(mx, fmaxf(fmaxf(st[ks][qt][0], st[ks][qt][1]), fmaxf(st[ks][qt][2], st[ks][qt][3])));
+      for (int ks = 1; ks < 4; ++ks) {
+        mx = max3f(mx, st[ks][qt][1], st[ks][qt][2]);
+        if (ks < 3) mx = max3f(mx, st[ks][qt][3], st[ks + 1][qt][0]);
+        else mx = fmaxf(mx, st[ks][qt][3]);
+      }
       mxl[qt] = mx;
     }
     const bool jump = !((mxl[0] - m[0]) * kc <= kDefer) || !((mxl[1] - m[1]) * kc <= kDefer);   // (m = -inf: true)
@@ -258,16 +268,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
       const float mc = -m[qt] * kc;
-      float ps = 0.f;
+      const f32x4 mc4 = f32x4{mc, mc, mc, mc}, kc4 = f32x4{kc, kc, kc, kc};
+      f32x4 ps4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x4 e = HAS_BIAS ? st[ks][qt] + mc4 : __builtin_elementwise_fma(st[ks][qt], kc4, mc4);   // packed fp32
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = fexp2<T>(fmaf(st[ks][qt][r], kc, mc));
-          st[ks][qt][r] = p;
-          ps += p;
-        }
-      lsum[qt] = lsum[qt] * alpha[qt] + ps;
+        for (int r = 0; r < 4; ++r) st[ks][qt][r] = fexp2<T>(e[r]);
+        ps4 += st[ks][qt];
+      }
+      lsum[qt] = lsum[qt] * alpha[qt] + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
     }
     // rescale O only when some query of this wave moved its maximum (wave-uniform branch)
     if (!__all(alpha[0] == 1.f && alpha[1] == 1.f)) {
