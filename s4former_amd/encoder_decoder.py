@@ -106,7 +106,7 @@ class BaseSegmentor(BaseModule):
                 raise TypeError(f'{name} is not a tensor or list of tensors')
         loss = sum(v for k, v in log_vars.items() if 'loss' in k)
         distributed = dist.is_available() and dist.is_initialized()
-        if distributed:
+        if distributed and not self.log_vars_as_tensors:   # (the key-count check reads a device scalar: a host sync per step)
             n = torch.tensor(len(log_vars), device=loss.device)
             dist.all_reduce(n)
             assert int(n) == len(log_vars) * dist.get_world_size(), \
