@@ -154,6 +154,9 @@ def main():
         reducer.broadcast_(model.teacher_store.flat)
     model.student_store.mark_dirty()
     reducer.attach(model.student_store)
+    if os.environ.get('S4F_EAGER_SGD', '1') != '0':
+        # parameter ranges are updated as soon as their (all-reduced) gradient is final, behind the rest of backward
+        opt.attach_eager(model.student_store, reducer if world > 1 else None, reducer.grad_scale())
 
     seg_gain = 1.0
     if n_unsup:
@@ -174,9 +177,12 @@ def main():
         opt.step(grad_scale=reducer.grad_scale())
         return out
 
-    # The critical chain (forward, input gradients, optimizer) runs on a high-priority HIP stream; the weight-gradient
-    # GEMMs of functional.py's side stream (priority 0) then only take the CUs the chain leaves idle.
-    main = torch.cuda.Stream(device=dev, priority=-1) if os.environ.get('S4F_MAIN_PRIORITY', '1') != '0' else None
+    # The critical chain (forward, input gradients, optimizer) runs on a stream of its own.  S4F_MAIN_PRIORITY=1 makes it a
+    # high-priority stream (round-1 experiment, no measurable gain any more) - NOT the default: with the high-priority
+    # chain + head streams, a FIFTH stream of normal priority (the gradient reducer's communication stream at N > 1, an
+    # optimiser stream) starves and the step goes from 32 to 40 ms (tools/exp/streams.sh); equal priorities do not.
+    prio = -1 if os.environ.get('S4F_MAIN_PRIORITY', '0') == '1' else 0
+    main = torch.cuda.Stream(device=dev, priority=prio)
     if main is not None:
         main.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main)

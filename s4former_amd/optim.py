@@ -7,6 +7,8 @@ never updated.  step() collapses the per-parameter groups back into one launch p
 groups of that range share their lr (they always do under the poly schedule).
 PolyLR: mmcv PolyLrUpdaterHook(by_epoch=False): lr_t = (lr_0 - min_lr) * (1 - t/T)^power + min_lr.
 """
+import os
+
 import torch
 
 from . import kernels as K
@@ -31,12 +33,18 @@ class S4FSGD(torch.optim.Optimizer):
         super().__init__(groups, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
         self.model = model
         self._ranges = None
+        self._plan_cache = None
+        self._eager = None           # (store, reducer, grad_scale) when ranges are stepped during backward
+        self._eager_done = []        # [(a, b)] arena ranges already stepped in this iteration
+        self._stream = None
 
     def _plan(self):
         """[(group_name, a, b, [param_group indices])] over the student arena"""
         store = self.model.student_store
         if store is None:
             raise S4FError('optimizer.step() before the first forward: the arenas do not exist yet')
+        if self._plan_cache is not None and self._plan_cache[0] is store:
+            return self._plan_cache
         pg_of = {id(g['params'][0]): i for i, g in enumerate(self.param_groups)}
         plan = []
         for gname, rng in store.group_ranges.items():
@@ -44,7 +52,62 @@ class S4FSGD(torch.optim.Optimizer):
             idx = [pg_of[id(e.module._parameters[e.attr])] for e in store.entries
                    if e.is_param and e.group == gname and id(e.module._parameters[e.attr]) in pg_of]
             plan.append((gname, a, b, idx))
+        self._plan_cache = (store, plan)
         return store, plan
+
+    # ------------------------------------------------------------------ eager mode
+    def attach_eager(self, store, reducer=None, grad_scale=1.0):
+        """Step every arena range as soon as its gradient is final (ParamStore.range_done: the end of an encoder layer's
+        or a head's backward) instead of after the whole backward: the HBM-bound update then runs behind the MFMA-bound
+        rest of the backward pass on its own stream.  Same kernels, same operands, same result; step() covers what is
+        left.  With a GradReducer the range is all-reduced first and stepped on the communication stream behind it."""
+        self._eager = (store, reducer, float(grad_scale))
+        store.on_range_done = self._range_done
+        return self
+
+    def _uniform(self, idx):
+        lrs = {self.param_groups[i]['lr'] for i in idx}
+        moms = {self.param_groups[i]['momentum'] for i in idx}
+        return (lrs.pop(), moms.pop()) if len(lrs) == 1 and len(moms) == 1 else None
+
+    @torch.no_grad()
+    def _range_done(self, a, b):
+        store, reducer, scale = self._eager
+        handle = None
+        if reducer is not None:
+            n0 = len(reducer._handles)
+            reducer._range_done(a, b)
+            if len(reducer._handles) > n0:
+                handle = reducer._handles[-1]
+        _, plan = self._plan()
+        hit = [(ga, gb, idx) for _, ga, gb, idx in plan if ga <= a and b <= gb]
+        lm = self._uniform(hit[0][2]) if hit else None
+        if lm is None or store.grad is None:
+            return                                   # mixed learning rates inside the group: left to step()
+        from .functional import extra_streams, side_stream
+        if handle is not None and reducer._stream is not None:
+            stream = reducer._stream                 # behind the all-reduce of this very range
+        else:
+            # the weight-gradient stream: the range's last weight-gradient kernels are already queued there (a FIFTH
+            # stream for this was measured: 32 -> 40 ms per step, like the third head stream)
+            stream = side_stream(store.flat.device)
+            if os.environ.get('S4F_EAGER_STREAM') == 'new':      # experiment: a stream of its own
+                if self._stream is None:
+                    self._stream = torch.cuda.Stream()
+                stream = self._stream
+            cur = torch.cuda.current_stream()
+            if stream != cur:
+                stream.wait_stream(cur)
+            for st in extra_streams():
+                if st != stream and st != cur:
+                    stream.wait_stream(st)
+        with torch.cuda.stream(stream):
+            if handle is not None:
+                handle.wait()
+            pt = store.flat_t[a:b] if store.flat_t is not None else None
+            K.sgd_momentum(store.flat[a:b], store.grad[a:b], store.mom[a:b], pt, b - a, lm[0], lm[1], scale,
+                           store.first_sgd_step, store.dtype)
+        self._eager_done.append((a, b, stream))
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
@@ -53,13 +116,21 @@ class S4FSGD(torch.optim.Optimizer):
         join_side_streams()          # weight-gradient kernels run on a side stream
         store, plan = self._plan()
         first = store.first_sgd_step
+        done = sorted((a, b) for a, b, _ in self._eager_done)
+        cur = torch.cuda.current_stream()
+        for st in {id(x[2]): x[2] for x in self._eager_done}.values():
+            cur.wait_stream(st)
+        self._eager_done = []
         for gname, a, b, idx in plan:
-            lrs = {self.param_groups[i]['lr'] for i in idx}
-            moms = {self.param_groups[i]['momentum'] for i in idx}
-            if len(lrs) == 1 and len(moms) == 1:
-                pt = store.flat_t[a:b] if store.flat_t is not None else None
-                K.sgd_momentum(store.flat[a:b], store.grad[a:b], store.mom[a:b], pt, b - a, lrs.pop(), moms.pop(),
-                               grad_scale, first, store.dtype)
+            lm = self._uniform(idx)
+            if lm is not None:
+                pos = a                               # what the eager mode has not stepped yet
+                for da, db in [d for d in done if a <= d[0] and d[1] <= b] + [(b, b)]:
+                    if da > pos:
+                        pt = store.flat_t[pos:da] if store.flat_t is not None else None
+                        K.sgd_momentum(store.flat[pos:da], store.grad[pos:da], store.mom[pos:da], pt, da - pos, lm[0], lm[1],
+                                       grad_scale, first, store.dtype)
+                    pos = max(pos, db)
             else:
                 for e in store.entries:
                     if not (e.is_param and e.group == gname):

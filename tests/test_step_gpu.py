@@ -167,3 +167,29 @@ def test_transposed_shadows_follow_the_weights():
     R, T, Cc = store._T_items[e0.off]
     ref = store.phys(prm).to(torch.bfloat16).view(R, T, Cc).permute(2, 1, 0).contiguous().view(-1)
     assert torch.equal(t.view(-1), ref)
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_eager_sgd_matches_the_plain_optimizer_step(dtype):
+    """S4FSGD.attach_eager steps every arena range as soon as its gradient is final (during backward, on the side stream);
+    step() covers the rest.  Same kernels and operands: three iterations end in the same weights, momentum and teacher up
+    to the run-to-run noise of the plain path itself (weight gradients accumulate through fp32 atomics: two plain fp32 runs
+    differ by up to 2.5e-5 in the momentum arena, `tools/exp/eager_debug.py`).  A range stepped twice, too early or not at
+    all would show as a difference of the order of its largest gradient, i.e. of the arena's scale."""
+    z, meta = load_gold('mt_pasa')
+    finals = []
+    for eager in (False, True):
+        model, opt, sched = build_product(meta, dtype)
+        model.ensure_engine(torch.device('cuda', 0))
+        if eager:
+            opt.attach_eager(model.student_store)
+        run_product(model, opt, sched, meta, iters=3)
+        if eager:
+            assert not opt._eager_done                       # consumed by step()
+        s, t = model.student_store, model.teacher_store
+        finals.append((s.flat.clone(), s.mom.clone(), t.flat.clone()))
+    for k, (p, e) in enumerate(zip(*finals)):
+        assert torch.isfinite(e).all()
+        diff = float((e - p).abs().max())
+        scale = float(p.abs().max())
+        assert diff <= (1e-3 if dtype == 'fp32' else 1e-2) * scale, (k, diff, scale)
