@@ -8,10 +8,12 @@ Scope: the supervised branch, the mean-teacher EMA, teacher pseudo-
 the pseudo-label CE (`compute_pseudo_loss`), and the PASA attention bias (rank-1, never materialised).
 CutMix / PatchShuffle / NCR / UniMatch / fdrop switches are "next" rows and raise.
 """
+import os
 from collections import OrderedDict
 from numbers import Number
 
 import numpy as np
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -124,6 +126,8 @@ class BaseSegmentor(BaseModule):
             log_vars[k] = v
         return loss, log_vars
 
+
+_UNSUP_STREAM = os.environ.get('S4F_UNSUP_STREAM', 'decode')    # experiment: 'decode2' = a third head stream
 
 _UNSUPPORTED_TRUE = ('sup_ema', 'attn_frozen', 'sup_ClassMix', 'sup_cutmix', 'unsup_soft', 'use_CutMix', 'use_CutOut',
                      'use_ClassMix', 'mix_with_labeled', 'patchwise', 'use_PatchShuffle', 'use_PatchShuffle_w_Classmix',
@@ -411,9 +415,10 @@ class EncoderDecoder(BaseSegmentor):
         self.losses.update(loss_decode_sup)
         # unsupervised heads (same order of head calls as the reference: sup, masked-unsup, plain-unsup); the loss
         # scalings stay on the decode head's stream with the losses they scale
-        # (a stream of its own for this second call of the decode head was measured: 42 ms instead of 34 - three conv-heavy
-        # streams evict each other's panels from L2; it shares the labelled call's stream)
-        with on_head_stream(simg.device, 'decode'):
+        # (a stream of its own for this second call of the decode head, S4F_UNSUP_STREAM=decode2, was measured: +0.4 ms with
+        # equal stream priorities - and 42 ms instead of 34 under a high-priority chain, see bench.py; it shares the
+        # labelled call's stream)
+        with on_head_stream(simg.device, _UNSUP_STREAM):
             loss_unsup = {}
             student_info = dict(img=simg, img_metas=stu['img_metas'], backbone_feature=f_mask)
             if self.attn_mask_seperate_head:
