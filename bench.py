@@ -177,12 +177,12 @@ def main():
         opt.step(grad_scale=reducer.grad_scale())
         return out
 
-    # The critical chain (forward, input gradients, optimizer) runs on a stream of its own.  S4F_MAIN_PRIORITY=1 makes it a
-    # high-priority stream (round-1 experiment, no measurable gain any more) - NOT the default: with the high-priority
-    # chain + head streams, a FIFTH stream of normal priority (the gradient reducer's communication stream at N > 1, an
-    # optimiser stream) starves and the step goes from 32 to 40 ms (tools/exp/streams.sh); equal priorities do not.
-    prio = -1 if os.environ.get('S4F_MAIN_PRIORITY', '0') == '1' else 0
-    main = torch.cuda.Stream(device=dev, priority=prio)
+    # The critical chain (forward, input gradients, optimizer) stays on the default stream (tools/exp/prio_ab.sh, ms per
+    # step on one box: default stream 32.6-32.7, a high-priority stream (S4F_MAIN_PRIORITY=1) 32.6-32.7, a created stream of
+    # normal priority (=0) 33.4-33.5).  The high-priority variant is NOT used: any fifth stream of normal priority (the
+    # gradient reducer's communication stream at N > 1, the eager-SGD stream) then starves: 40.5 ms.
+    mode = os.environ.get('S4F_MAIN_PRIORITY', 'default')
+    main = None if mode == 'default' else torch.cuda.Stream(device=dev, priority=-1 if mode == '1' else 0)
     if main is not None:
         main.wait_stream(torch.cuda.current_stream())
         torch.cuda.set_stream(main)

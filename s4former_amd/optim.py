@@ -88,13 +88,15 @@ class S4FSGD(torch.optim.Optimizer):
         if handle is not None and reducer._stream is not None:
             stream = reducer._stream                 # behind the all-reduce of this very range
         else:
-            # the weight-gradient stream: the range's last weight-gradient kernels are already queued there (a FIFTH
-            # stream for this was measured: 32 -> 40 ms per step, like the third head stream)
-            stream = side_stream(store.flat.device)
-            if os.environ.get('S4F_EAGER_STREAM') == 'new':      # experiment: a stream of its own
+            # a stream of its own (32.45 vs 32.65 ms per step on the weight-gradient stream) - unless the caller's chain runs
+            # on a high-priority stream: a fifth stream of normal priority then starves (32 -> 40 ms, tools/exp/prio_ab.sh)
+            cur = torch.cuda.current_stream()
+            if os.environ.get('S4F_EAGER_STREAM', 'new') == 'new' and cur.priority >= 0:
                 if self._stream is None:
                     self._stream = torch.cuda.Stream()
                 stream = self._stream
+            else:
+                stream = side_stream(store.flat.device)
             cur = torch.cuda.current_stream()
             if stream != cur:
                 stream.wait_stream(cur)
