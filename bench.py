@@ -177,6 +177,9 @@ def main():
         opt.step(grad_scale=reducer.grad_scale())
         return out
 
+    # Hardware queues: the step is fastest with exactly FOUR (GPU_MAX_HW_QUEUES, the runtime's default; measured ms per
+    # step at 2 / 3 / 4 / 5 queues: 35.7 / 34.1 / 32.65 / 40.5).  A fifth queue is a cliff - and a high-priority HIP stream
+    # opens one beyond the pool of four, which is what made "one more stream" cost 8 ms under a high-priority chain.
     # The critical chain (forward, input gradients, optimizer) stays on the default stream (tools/exp/prio_ab.sh, ms per
     # step on one box: default stream 32.6-32.7, a high-priority stream (S4F_MAIN_PRIORITY=1) 32.6-32.7, a created stream of
     # normal priority (=0) 33.4-33.5).  The high-priority variant is NOT used: any fifth stream of normal priority (the
