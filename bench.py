@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '0')   # a high-priority stream opens a FIFTH hardware queue: +8 ms per step
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}      # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
 WORKLOADS = {
@@ -154,6 +155,9 @@ def main():
         reducer.broadcast_(model.teacher_store.flat)
     model.student_store.mark_dirty()
     reducer.attach(model.student_store)
+    if world > 1 and os.environ.get('S4F_STREAM_LAYOUT', '1') != '0':
+        from s4former_amd.functional import lay_out_streams
+        reducer._stream = lay_out_streams(dev)      # collectives + eager SGD issue from the weight-gradient stream
     if os.environ.get('S4F_EAGER_SGD', '1') != '0':
         # parameter ranges are updated as soon as their (all-reduced) gradient is final, behind the rest of backward
         opt.attach_eager(model.student_store, reducer if world > 1 else None, reducer.grad_scale())

@@ -65,10 +65,13 @@ class GradReducer:
             return _Null()
         if self._stream is None:
             self._stream = torch.cuda.Stream()
-        self._stream.wait_stream(torch.cuda.current_stream())
+        cur = torch.cuda.current_stream()
+        if cur != self._stream:
+            self._stream.wait_stream(cur)
         from .functional import extra_streams
         for st in extra_streams():
-            self._stream.wait_stream(st)              # weight-gradient kernels / heads run on their own streams
+            if st != self._stream:                    # (the communication stream may BE the weight-gradient stream)
+                self._stream.wait_stream(st)          # weight-gradient kernels / heads run on their own streams
         return torch.cuda.stream(self._stream)
 
     def _launch(self, t):
