@@ -155,6 +155,13 @@ def main():
         reducer.broadcast_(model.teacher_store.flat)
     model.student_store.mark_dirty()
     reducer.attach(model.student_store)
+    if world == 1 and os.environ.get('S4F_STREAM_LAYOUT') == 'test':
+        # rehearsal of the N > 1 layout on one GPU: a stand-in for RCCL's stream takes pool index 0 (tools/exp/queue_map.py)
+        from s4former_amd.functional import lay_out_streams
+        _standin = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(_standin):
+            torch.empty(1 << 20, device=dev).fill_(1.0)
+        lay_out_streams(dev)
     if world > 1 and os.environ.get('S4F_STREAM_LAYOUT', '1') != '0':
         from s4former_amd.functional import lay_out_streams
         reducer._stream = lay_out_streams(dev)      # collectives + eager SGD issue from the weight-gradient stream

@@ -50,18 +50,25 @@ def head_stream(device, name, priority=0):
 
 
 def lay_out_streams(device):
-    """N > 1 only, after the first collective (ProcessGroupNCCL has then taken stream 0 of torch's pool).  The runtime spreads
-    the pool's streams over its FOUR hardware queues in a fixed pattern (measured with tools/exp/queue_map.py: pool index
-    0 1 2 3 4 5 6 ... -> queue 2 3 4 4 3 2 1 ..., the default stream owns queue 1) and two streams on one queue serialise.
-    Wanted: the chain alone on queue 1, the decode / auxiliary head streams alone on queues 3 / 4, and the weight-gradient
-    stream - which then also issues the gradient all-reduces and the eager SGD - on queue 2 WITH RCCL's stream: both are
-    off the critical chain.  Creation order decode (1), aux (2), two unused (3, 4), side (5) gives exactly that; with the
-    lazy creation order (side = 3) the weight gradients would share queue 4 with the auxiliary heads.  Returns the side
-    stream (the reducer's communication stream).  A wrong guess about the pattern only changes which streams share."""
-    head_stream(device, 'decode')
-    head_stream(device, 'aux')
+    """N > 1 only, after the first collective (RCCL's stream has then been USED first).  The runtime has FOUR hardware
+    queues; the default stream owns queue 1 and every other stream is bound at its first use, in the fixed pattern
+    2 3 4 4 3 2 1 4 ... (tools/exp/queue_map.py); two streams on one queue serialise.  Wanted: the chain alone on queue 1,
+    the decode / auxiliary head streams alone on queues 3 / 4, and the weight-gradient stream - which then also issues the
+    gradient all-reduces and the eager SGD - on queue 2 WITH RCCL's stream: both are off the critical chain.  First-use
+    order RCCL, decode, aux, two throw-away streams, side gives exactly that (rehearsed on one GPU with a stand-in for
+    RCCL: S4F_STREAM_LAYOUT=test); left alone, the weight gradients (4th stream used) share queue 4 with the auxiliary
+    heads.  Returns the side stream (the reducer's communication stream).  A wrong guess only changes who shares."""
+    def touch(st):
+        with torch.cuda.stream(st):
+            torch.empty(64, device=device).fill_(0.0)
+
     if torch.device(device).index not in _side:
-        _burn.extend(torch.cuda.Stream(device=device) for _ in range(2))
+        touch(head_stream(device, 'decode'))
+        touch(head_stream(device, 'aux'))
+        for _ in range(2):
+            _burn.append(torch.cuda.Stream(device=device))
+            touch(_burn[-1])
+        touch(side_stream(device))
     return side_stream(device)
 
 
