@@ -88,7 +88,8 @@ class S4FSGD(torch.optim.Optimizer):
         if handle is not None and reducer._stream is not None:
             stream = reducer._stream                 # behind the all-reduce of this very range
         else:
-            # a stream of its own (32.45 vs 32.65 ms per step on the weight-gradient stream) - unless the caller's chain runs
+            # a stream of its own (32.45 vs 32.65 ms per step on the weight-gradient stream; as the 4th stream used it shares
+            # the weight gradients' hardware queue - on the head streams' queues it was measured slower) - unless the chain runs
             # on a high-priority stream: a fifth stream of normal priority then starves (32 -> 40 ms, tools/exp/prio_ab.sh)
             cur = torch.cuda.current_stream()
             if os.environ.get('S4F_EAGER_STREAM', 'new') == 'new' and cur.priority >= 0:
