@@ -155,13 +155,15 @@ def main():
         reducer.broadcast_(model.teacher_store.flat)
     model.student_store.mark_dirty()
     reducer.attach(model.student_store)
-    if world == 1 and os.environ.get('S4F_STREAM_LAYOUT') == 'test':
-        # rehearsal of the N > 1 layout on one GPU: a stand-in for RCCL's stream takes pool index 0 (tools/exp/queue_map.py)
-        from s4former_amd.functional import lay_out_streams
-        _standin = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(_standin):
+    if world == 1 and os.environ.get('S4F_STREAM_LAYOUT', '').startswith('test'):
+        # rehearsal of the N > 1 stream layouts on one GPU: a stand-in for RCCL's stream is the first stream used (hardware
+        # queue 2) and runs a small kernel wherever SyncBN would all-reduce; 'test' = deliberate layout, 'test_lazy' = none
+        import s4former_amd.functional as F_
+        F_.STANDIN = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(F_.STANDIN):
             torch.empty(1 << 20, device=dev).fill_(1.0)
-        lay_out_streams(dev)
+        if os.environ['S4F_STREAM_LAYOUT'] == 'test':
+            F_.lay_out_streams(dev)
     if world > 1 and os.environ.get('S4F_STREAM_LAYOUT', '1') != '0':
         from s4former_amd.functional import lay_out_streams
         reducer._stream = lay_out_streams(dev)      # collectives + eager SGD issue from the weight-gradient stream

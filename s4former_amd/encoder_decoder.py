@@ -278,12 +278,40 @@ class EncoderDecoder(BaseSegmentor):
     def _auxiliary_head_forward_train(self, x, img_metas, gt_semantic_seg):
         losses = dict()
         with on_head_stream(gt_semantic_seg.device, 'aux'):
-            if isinstance(self.auxiliary_head, nn.ModuleList):
+            if isinstance(self.auxiliary_head, nn.ModuleList) and self._aux_lockstep():
+                # N > 1: the structurally identical auxiliary heads advance layer by layer TOGETHER, one SyncBN exchange
+                # per layer for all of them (16 -> 4 per step); same arithmetic per head
+                heads = list(self.auxiliary_head)
+                outs = type(heads[0]).forward_train_lockstep(heads, x, img_metas, gt_semantic_seg, self.train_cfg)
+                for idx, o in enumerate(outs):
+                    losses.update(add_prefix(o, f'aux_{idx}'))
+            elif isinstance(self.auxiliary_head, nn.ModuleList):
                 for idx, aux_head in enumerate(self.auxiliary_head):
                     losses.update(add_prefix(aux_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), f'aux_{idx}'))
             else:
                 losses.update(add_prefix(self.auxiliary_head.forward_train(x, img_metas, gt_semantic_seg, self.train_cfg), 'aux'))
         return losses
+
+    def _aux_lockstep(self):
+        mode = os.environ.get('S4F_AUX_LOCKSTEP', 'auto')
+        if mode == '0':
+            return False
+        heads = list(self.auxiliary_head)
+        same = len(heads) > 1 and all(hasattr(type(h), 'forward_train_lockstep') for h in heads) and \
+            len({(h.num_convs, h.channels, h.up_scale) for h in heads}) == 1
+        if not same:
+            return False
+        if mode == '1':
+            return True
+        from . import functional as F_
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        return distributed or F_.STANDIN is not None
+
+    def _decode_lockstep(self):
+        """S4F_DECODE_LOCKSTEP=1: the decode head's calls of a step advance in lockstep too (8 fewer SyncBN exchanges).  Off by
+        default: in the one-GPU rehearsal (no network latency) the interleaved large tensors cost 0.36 ms more than the
+        saved round trips give back; to be re-measured on a multi-GPU node."""
+        return os.environ.get('S4F_DECODE_LOCKSTEP', '0') == '1' and hasattr(type(self.decode_head), 'fused_losses_lockstep')
 
     # ------------------------------------------------------------------ EMA
     def update_ema_variables(self, model=None, ema_model=None, momentum=None, dropout=0.0, attn_frozen=False):
@@ -408,6 +436,38 @@ class EncoderDecoder(BaseSegmentor):
         outs = self.backbone.forward_rank1(imgs, (bias_u, row_flag, w))
         f_sup = self.backbone.split_taps(outs, 0, ns)
         f_mask = self.backbone.split_taps(outs, ns, ns + nu)
+        if self._decode_lockstep():
+            # N > 1: the decode head's calls (labelled, masked pseudo-labelled, plain pseudo-labelled) advance layer by layer
+            # TOGETHER: one SyncBN exchange per layer for all of them; BN running statistics are updated in call order
+            dh = self.decode_head
+            pseudo = teacher_info['hard_seg_label']
+            calls = [(dh, f_sup, dh._loss_labels(sup['img_metas'], sup['gt_semantic_seg']), dh.loss_decode.loss_weight),
+                     (dh, f_mask, pseudo, 1.0)]
+            if self.attn_mask_seperate_head:
+                calls.append((dh, self.backbone.split_taps(outs, ns + nu, ns + 2 * nu), pseudo, 1.0))
+            with on_head_stream(simg.device, 'decode'):
+                dl = type(dh).fused_losses_lockstep(calls)
+                loss_decode_sup = add_prefix({dh.loss_decode.loss_name: dl[0]}, 'decode')
+                loss_unsup = {}
+                if self.attn_mask_seperate_head:
+                    loss_unsup['loss_seg_unsup_attn_mask'] = dl[1] * 0.5
+                loss_unsup['loss_seg_unsup'] = dl[-1] * self.fdrop_loss_weight
+                if self.unsup_confidence != 0:
+                    self.last_mask_ratio = teacher_info['conf_count'].to(torch.float32) / pseudo.numel()
+                unsup_loss = weighted_loss(loss_unsup, weight=self.unsup_weight)
+            if self.with_auxiliary_head:
+                self.losses.update(self._auxiliary_head_forward_train(f_sup, sup['img_metas'], sup['gt_semantic_seg']))
+            self.losses.update(loss_decode_sup)
+        else:
+            self._fused_heads_sequential(sup, stu, simg, outs, f_sup, f_mask, ns, nu, teacher_info)
+            return
+        if self.iter_unsup_start != 0:
+            if self.current_iter > self.iter_unsup_start:
+                self.losses.update(unsup_loss)
+        else:
+            self.losses.update(unsup_loss)
+
+    def _fused_heads_sequential(self, sup, stu, simg, outs, f_sup, f_mask, ns, nu, teacher_info):
         # supervised heads
         loss_decode_sup = self._decode_head_forward_train(f_sup, sup['img_metas'], sup['gt_semantic_seg'])
         if self.with_auxiliary_head:

@@ -73,6 +73,16 @@ def lay_out_streams(device):
 
 
 _burn = []
+STANDIN = None                 # rehearsal of the N > 1 stream layout on one GPU: a stream standing in for RCCL's
+
+
+def _rehearse_allreduce(t):
+    """what a SyncBN all-reduce does to the queues: RCCL's stream waits for the caller's, runs a small kernel, the caller waits"""
+    cur = torch.cuda.current_stream()
+    STANDIN.wait_stream(cur)
+    with torch.cuda.stream(STANDIN):
+        t.add_(0.0)
+    cur.wait_stream(STANDIN)
 
 
 def extra_streams(device=None):
@@ -389,7 +399,63 @@ def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
 
 
+class _Exchange:
+    """SyncBN statistics exchange of one or several heads advancing in lockstep.  Every head takes its 2 C floats from ONE
+    buffer per round (alloc), fills them, and yields; when all heads of the round have yielded, the buffer crosses the
+    ranks in ONE all-reduce.  With a single head this is the plain per-layer all-reduce."""
+
+    def __init__(self, nheads, world):
+        self.n, self.world = nheads, world
+        self.buf, self.i = None, 0
+
+    def alloc(self, size, dev):
+        if self.buf is None or self.i >= self.n:
+            self.buf, self.i = zeros_small(self.n * size, dev), 0
+        v = self.buf[self.i * size:(self.i + 1) * size]
+        self.i += 1
+        return v
+
+    def reduce(self):
+        if self.buf is None:
+            return
+        if self.world > 1:
+            dist.all_reduce(self.buf)
+        elif STANDIN is not None:
+            _rehearse_allreduce(self.buf)
+        self.buf = None
+
+
+def _drive(gens, ex):
+    """advance the generators in lockstep: one ex.reduce() per round of yields; returns their return values"""
+    out = [None] * len(gens)
+    live = list(range(len(gens)))
+    while live:
+        nxt = []
+        for i in live:
+            try:
+                next(gens[i])
+                nxt.append(i)
+            except StopIteration as e:
+                out[i] = e.value
+        if nxt:
+            if len(nxt) != len(live):
+                raise S4FError('lockstep heads must have the same number of SyncBN layers')
+            ex.reduce()
+        live = nxt
+    return out
+
+
 def head_forward(tokens, hp, store, training, save):
+    world = _world() if (hp['sync_bn'] and training) else 1
+    return _run_one(_head_forward_gen, tokens, hp, store, training, save, world=world)
+
+
+def _run_one(gen_fn, *args, world):
+    ex = _Exchange(1, world)
+    return _drive([gen_fn(*args, ex)], ex)[0]
+
+
+def _head_forward_gen(tokens, hp, store, training, save, ex):
     """LN -> [conv3x3 -> (Sync)BN -> ReLU -> up]*n -> conv_seg (before the last upsample) -> low-res logits.
     tokens: fp32 [B, T+1, E] (cls first; dropped here).  hp: dict with the head's parameters/buffers/config.
     Returns (logits_lo fp32 [B*h*w, LOGIT_LD], (B, h, w), saved or None)."""
@@ -427,10 +493,9 @@ def head_forward(tokens, hp, store, training, save):
         mean = torch.empty(Cc, device=dev); rstd = torch.empty(Cc, device=dev)
         count = float(Mp) * world
         if training:
-            sums = zeros_small(2 * Cc, dev)
+            sums = ex.alloc(2 * Cc, dev)
             K.bn_stats(y, Mp, Cc, sums, code)
-            if world > 1:
-                dist.all_reduce(sums)
+            yield                                            # the statistics cross the ranks (lockstep heads: together)
             K.bn_finalize(sums, count, store.phys(cv['bn_w']), store.phys(cv['bn_b']), store.phys(cv['rm']),
                           store.phys(cv['rv']), hp['bn_momentum'], hp['bn_eps'], True, scale, shift, mean, rstd, Cc)
             cv['nbt'][0] += 1
@@ -457,6 +522,10 @@ def head_forward(tokens, hp, store, training, save):
 
 def head_backward(dlo, dlo_t, sv, hp, store):
     """gradients of everything upstream of the low-res logits; returns d tokens (fp32 [B, T+1, E])."""
+    return _run_one(_head_backward_gen, dlo, dlo_t, sv, hp, store, world=_world() if hp['sync_bn'] else 1)
+
+
+def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
     code = store.dtype
     T = _T(code)
     tokens = sv['tokens']
@@ -477,7 +546,7 @@ def head_backward(dlo, dlo_t, sv, hp, store):
         cv, st = hp['convs'][k], sv['stages'][k]
         Cc, h, w, s, cin_k = st['Cc'], st['h'], st['w'], st['s'], st['cin']
         Mk = Bn * h * w
-        bsums = zeros_small(2 * Cc, dev)
+        bsums = ex.alloc(2 * Cc, dev)
         dy = torch.empty(Mk, Cc, device=dev, dtype=T)
         if s == 1 and SKIP_MASKED_COPY:
             # no upsample: the masked gradient g = dcur * relu' is not materialised; the statistics pass and the apply pass
@@ -489,8 +558,7 @@ def head_backward(dlo, dlo_t, sv, hp, store):
             K.bn_relu_up_bwd(dcur, st['y'], st['scale'], st['shift'], st['mean'], st['rstd'], g, bsums, Bn, h, w, Cc, s, code)
             rs = rb = None
         K.bn_param_grads(bsums, store.grad_phys(cv['bn_w']), store.grad_phys(cv['bn_b']), Cc)
-        if world > 1:
-            dist.all_reduce(bsums)
+        yield                                                # the sums cross the ranks (lockstep heads: together)
         K.bn_bwd_apply(g, st['y'], st['mean'], st['rstd'], store.phys(cv['bn_w']), bsums, st['count'], dy, Mk, Cc, code,
                        relu_scale=rs, relu_shift=rb)
         del g
@@ -578,3 +646,79 @@ class HeadLossFn(Function):
         if hp['_pending'] == 0:
             store.range_done(*ctx.range)
         return (dtok, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+
+
+class MultiHeadLossFn(Function):
+    """The fused losses of several structurally identical head CALLS (the four auxiliary heads; the decode head's labelled
+    and pseudo-labelled calls) advancing in LOCKSTEP: layer k of every call, then ONE SyncBN all-reduce for all of them,
+    instead of one per call and layer (32 -> 12 exchanges per step; each exchange is a round trip between the head's
+    stream and RCCL's).  Per call the arithmetic, the kernels and their order are those of HeadLossFn; calls of the SAME
+    head update its BN running statistics layer by layer in call order, as consecutive calls do."""
+
+    @staticmethod
+    def forward(ctx, store, metas, *tensors):
+        n = len(metas)                                   # metas[i] = (loss_weight, hp, number of parameters, labels u8)
+        tokens = tensors[:n]
+        need_grad = any(ctx.needs_input_grad)
+        world = _world() if (metas[0][1]['sync_bn'] and metas[0][1]['training']) else 1
+        ex = _Exchange(n, world)
+        labels_u8 = None
+        outs = _drive([_head_forward_gen(tokens[i], metas[i][1], store, metas[i][1]['training'], need_grad, ex)
+                       for i in range(n)], ex)
+        losses, saved = [], []
+        off = n
+        for i in range(n):
+            lw, hp, nprm, labels_u8 = metas[i]
+            logits, (Bn, h, w), sv = outs[i]
+            s = hp['up_scale']
+            H, W = h * s, w * s
+            if tuple(labels_u8.shape) != (Bn, H, W):
+                raise S4FError(f'labels {tuple(labels_u8.shape)} do not match the logits size {(Bn, H, W)}')
+            loss_sum = zeros_small(1, tokens[i].device)
+            lse = torch.empty(Bn, H, W, device=tokens[i].device) if need_grad and s in (2, 4) else None
+            K.upce_fwd(logits, labels_u8, loss_sum, Bn, h, w, hp['num_classes'], LOGIT_LD, s, hp['ignore_index'], lse_out=lse)
+            k = float(lw) / float(Bn * H * W)
+            losses.append((loss_sum * k).reshape(()))
+            if need_grad:
+                ep = getattr(store, 'step_epoch', 0)
+                if hp.get('_epoch') != ep:
+                    hp['_epoch'], hp['_pending'] = ep, 0
+                hp['_pending'] += 1
+                saved.append(dict(sv=sv, hp=hp, meta=(k, Bn, h, w, s), lse=lse, labels=labels_u8,
+                                  range=store.range_of(tensors[off:off + nprm])))
+            off += nprm
+        if need_grad:
+            ctx.saved, ctx.store, ctx.n = saved, store, n
+            ctx.consumer = GRAD_CONSUMER
+        return tuple(losses)
+
+    @staticmethod
+    def backward(ctx, *dlosses):
+        store, n = ctx.store, ctx.n
+        code = store.dtype
+        gens = []
+        for i in range(n):
+            sd = ctx.saved[i]
+            sv, hp = sd['sv'], sd['hp']
+            k, Bn, h, w, s = sd['meta']
+            logits = sv['logits']
+            dlo = torch.empty_like(logits)
+            dlo_t = torch.empty(logits.shape, device=logits.device, dtype=torch.bfloat16) if code == BF16 else None
+            gdev = dlosses[i].detach().reshape(1).to(torch.float32).contiguous()
+            K.upce_bwd(logits, sd['labels'], k, dlo, dlo_t, Bn, h, w, hp['num_classes'], LOGIT_LD, s, code, hp['ignore_index'],
+                       gscale_dev=gdev, lse=sd['lse'])
+            sd['lse'] = None
+            gens.append((dlo, dlo_t if dlo_t is not None else dlo, sv, hp))
+        world = _world() if ctx.saved[0]['hp']['sync_bn'] else 1
+        ex = _Exchange(n, world)
+        dtoks = _drive([_head_backward_gen(a, b, sv, hp, store, ex) for a, b, sv, hp in gens], ex)
+        for i in range(n):
+            if ctx.consumer is not None:
+                dtoks[i].record_stream(ctx.consumer)
+            hp = ctx.saved[i]['hp']
+            store.node_done()
+            hp['_pending'] = hp.get('_pending', 1) - 1
+            if hp['_pending'] == 0:
+                store.range_done(*ctx.saved[i]['range'])
+        ctx.saved = None
+        return (None, None) + tuple(dtoks) + (None,) * (len(ctx.needs_input_grad) - 2 - n)

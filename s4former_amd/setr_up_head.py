@@ -230,6 +230,46 @@ class SETRUPHead(BaseDecodeHead):
         tokens, grid = self._tokens_of(x)
         return HeadLossFn.apply(tokens, labels_u8, loss_weight, self._hp(grid), store, *self._params())
 
+    def _loss_labels(self, img_metas, gt_semantic_seg):
+        if img_metas and 'PatchMix_N' in img_metas[0]:
+            raise S4FError('PatchMix un-shuffle belongs to the "ours" additions (SURVEY §8f-1)')
+        ld = self.loss_decode
+        if isinstance(ld, nn.ModuleList) or not isinstance(ld, CrossEntropyLoss) or ld.class_weight is not None \
+                or ld.reduction != 'mean' or ld.avg_non_ignore:
+            raise S4FError('the fused head loss implements CrossEntropyLoss(reduction="mean", avg_non_ignore=False)')
+        labels = gt_semantic_seg
+        if labels.dim() == 4:
+            labels = labels.squeeze(1)
+        if labels.dtype != torch.uint8:
+            labels = labels.to(torch.uint8)
+        return labels.contiguous()
+
+    @staticmethod
+    def fused_losses_lockstep(calls):
+        """calls = [(head, inputs, labels_u8, loss_weight)] of structurally identical heads (or of one head, several times):
+        ONE autograd node whose SyncBN layers exchange their statistics together (functional.MultiHeadLossFn).  Returns
+        the loss tensors in call order."""
+        from .functional import MultiHeadLossFn
+        toks, metas, prms = [], [], []
+        store = None
+        for hd, inputs, labels_u8, lw in calls:
+            x = hd._transform_inputs(inputs)
+            store = hd._ensure_store(x.device)
+            tokens, grid = hd._tokens_of(x)
+            p_ = hd._params()
+            toks.append(tokens)
+            metas.append((lw, hd._hp(grid), len(p_), labels_u8))
+            prms.extend(p_)
+        return list(MultiHeadLossFn.apply(store, metas, *toks, *prms))
+
+    @staticmethod
+    def forward_train_lockstep(heads, inputs, img_metas, gt_semantic_seg, train_cfg):
+        """forward_train of several structurally identical heads on the same inputs and labels, in lockstep; returns the
+        per-head loss dicts in order."""
+        labels = [hd._loss_labels(img_metas, gt_semantic_seg) for hd in heads]
+        losses = SETRUPHead.fused_losses_lockstep([(hd, inputs, lb, hd.loss_decode.loss_weight) for hd, lb in zip(heads, labels)])
+        return [{hd.loss_decode.loss_name: l} for hd, l in zip(heads, losses)]
+
     def forward_train(self, inputs, img_metas, gt_semantic_seg, train_cfg):
         """decode_head.py:225-259 + losses (:318-355) in one fused node."""
         if img_metas and 'PatchMix_N' in img_metas[0]:

@@ -193,3 +193,25 @@ def test_eager_sgd_matches_the_plain_optimizer_step(dtype):
         diff = float((e - p).abs().max())
         scale = float(p.abs().max())
         assert diff <= (1e-3 if dtype == 'fp32' else 1e-2) * scale, (k, diff, scale)
+
+
+@pytest.mark.parametrize('name', ['sup', 'mt_pasa'])
+def test_lockstep_heads_match_the_sequential_heads(name, monkeypatch):
+    """N > 1 runs the four auxiliary heads (and optionally the decode head's calls) layer by layer in lockstep so that their
+    SyncBN statistics cross the ranks in one all-reduce per layer (functional.MultiHeadLossFn).  Per head the arithmetic is
+    unchanged: on one rank the losses and gradients must match the sequential heads (fp32: to atomics noise)."""
+    z, meta = load_gold(name)
+    recs = []
+    for lock in ('0', '1'):
+        monkeypatch.setenv('S4F_AUX_LOCKSTEP', lock)
+        monkeypatch.setenv('S4F_DECODE_LOCKSTEP', lock)
+        model, opt, sched = build_product(meta, 'fp32')
+        recs.append(run_product(model, opt, sched, meta, iters=2))
+    for it in range(2):
+        a, b = recs[0][it], recs[1][it]
+        assert list(a['log']) == list(b['log'])
+        for k in a['log']:
+            assert abs(float(a['log'][k]) - float(b['log'][k])) <= 1e-5 * abs(float(a['log'][k])) + 1e-7, (it, k)
+        assert set(a['gn']) == set(b['gn'])
+        for n in a['gn']:
+            assert abs(a['gn'][n] - b['gn'][n]) <= 1e-4 * a['gn'][n] + 1e-9, (it, n, a['gn'][n], b['gn'][n])
