@@ -163,13 +163,14 @@ def main():
         with torch.cuda.stream(F_.STANDIN):
             torch.empty(1 << 20, device=dev).fill_(1.0)
         if os.environ['S4F_STREAM_LAYOUT'] == 'test':
-            F_.lay_out_streams(dev)
+            reducer._stream = F_.lay_out_streams(dev)
     if world > 1 and os.environ.get('S4F_STREAM_LAYOUT', '1') != '0':
         from s4former_amd.functional import lay_out_streams
         reducer._stream = lay_out_streams(dev)      # collectives + eager SGD issue from the weight-gradient stream
     if os.environ.get('S4F_EAGER_SGD', '1') != '0':
         # parameter ranges are updated as soon as their (all-reduced) gradient is final, behind the rest of backward
-        opt.attach_eager(model.student_store, reducer if world > 1 else None, reducer.grad_scale())
+        rehearse = os.environ.get('S4F_STREAM_LAYOUT', '').startswith('test')
+        opt.attach_eager(model.student_store, reducer if (world > 1 or rehearse) else None, reducer.grad_scale())
 
     seg_gain = 1.0
     if n_unsup:

@@ -76,17 +76,20 @@ class GradReducer:
 
     def _launch(self, t):
         with self._comm_ctx(t):
-            self._handles.append(dist.all_reduce(t, async_op=True))
+            if _rehearsal() is not None:
+                self._handles.append(_StandInWork(t))
+            else:
+                self._handles.append(dist.all_reduce(t, async_op=True))
 
     def _range_done(self, a, b):
-        if world_size() == 1 or self._store is None or self._store.grad is None:
+        if (world_size() == 1 and _rehearsal() is None) or self._store is None or self._store.grad is None:
             return
         self._launch(self._store.grad[a:b])
         self._done.append((a, b))
 
     def reduce_(self, flat_grad):
         """launch the all-reduces of every range not yet reduced in this step; call wait() before the optimiser step"""
-        if world_size() == 1:
+        if world_size() == 1 and _rehearsal() is None:
             self._done = []
             return
         n = flat_grad.numel()
@@ -112,6 +115,31 @@ class GradReducer:
 
     def grad_scale(self):
         return 1.0 / world_size()
+
+
+def _rehearsal():
+    """one-GPU rehearsal of the N > 1 control flow (bench.py, S4F_STREAM_LAYOUT=test): the stream standing in for RCCL's"""
+    if world_size() > 1:
+        return None
+    from . import functional as F_
+    return F_.STANDIN
+
+
+class _StandInWork:
+    """what an asynchronous all-reduce does to the streams, without peers: RCCL's stream waits for the issuing stream, passes
+    over the buffer twice (a ring all-reduce reads and writes it about that often), and wait() makes the caller's stream
+    wait for it"""
+
+    def __init__(self, t):
+        st = _rehearsal()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            t.mul_(1.0)
+            t.mul_(1.0)
+        self._st = st
+
+    def wait(self):
+        torch.cuda.current_stream().wait_stream(self._st)
 
 
 class _Null:
