@@ -25,6 +25,8 @@ if ROOT not in sys.path:
 os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '0')   # a high-priority stream opens a FIFTH hardware queue: +8 ms per step
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}      # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 
+_WD_FILE = None
+TINY = dict(embed=256, layers=4, heads=4, channels=128, out_indices=(0, 1, 2, 3))   # the tests' scaled-down model
 WORKLOADS = {
     # name: (n_sup, n_unsup, img, classes, model flags, description)
     'sup': (8, 0, 512, 21, dict(unsup_weight=0), 'cfg2: SETR DeiT-B PUP supervised-only bs=8 512x512 (EMA on, unsup_weight=0)'),
@@ -32,6 +34,8 @@ WORKLOADS = {
              'cfg3/4: S4Former mean-teacher semi 8+8 512x512 th=0.95, pseudo-label CE enabled'),
     'semi768': (4, 4, 768, 19, dict(unsup_weight=1.0, plain_mt_pseudo_loss=True),
                 'cfg5: S4Former Cityscapes 768x768 4+4, pseudo-label CE enabled'),
+    # not a benchmark: the N > 1 control flow of this very script on a model that steps in milliseconds (tests/test_zz_dist_gpu.py)
+    'tiny': (2, 2, 64, 21, dict(unsup_weight=1.0, plain_mt_pseudo_loss=True, **TINY), 'test-only: tiny SETR-PUP 2+2 64x64'),
 }
 
 
@@ -64,7 +68,7 @@ def usable_cores():
 
 def cpu_baseline():
     """the oracle (CPU restatement of the reference step) timed on this box's host cores: cfg1 = DeiT-B PUP
-    supervised-only semantics (EMA on), bs 2, 512x512, SGD momentum; 1 warm-up + 1 timed step."""
+    supervised-only semantics (EMA on), bs 2, 512x512, SGD momentum; 1 warm-up + median of 3 timed steps."""
     from oracle import model as OM
     from s4former_amd.presets import setr_pup_model, synthetic_batch
     cores = usable_cores()
@@ -77,7 +81,7 @@ def cpu_baseline():
     imgs, gt, metas = synthetic_batch(1999, 2, 0)
     tags = [m['tag'] for m in metas]
     times = []
-    for it in range(2):
+    for it in range(4):
         t0 = time.time()
         OM.set_poly_lr(opt, it)
         opt.zero_grad()
@@ -85,10 +89,11 @@ def cpu_baseline():
         loss.backward()
         opt.step()
         times.append(time.time() - t0)
-    return dict(value=round(2.0 / times[-1], 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
+    med = sorted(times[1:])[1]
+    return dict(value=round(2.0 / med, 4), unit='images/s', cores=torch.get_num_threads(), kind='port',
                 sample='cfg1: DeiT-B PUP sup-only (EMA on) bs=2 512x512 fp32, oracle (torch CPU restatement of the '
-                       'reference step), 1 warm-up + 1 timed step', seconds_per_step=round(times[-1], 2),
-                torch=torch.__version__)
+                       'reference step), 1 warm-up + median of 3 timed steps', seconds_per_step=round(med, 2),
+                seconds_per_step_all=[round(t, 2) for t in times], torch=torch.__version__)
 
 
 def calibrate_teacher(model, batch, n_sup, n_unsup, target):
@@ -122,13 +127,20 @@ def main():
     args = parse()
     import s4former_amd as S
     from s4former_amd import _lib
-    from s4former_amd.dist import GradReducer, init_distributed
+    from s4former_amd.dist import init_distributed, setup_data_parallel
     from s4former_amd.functional import join_side_streams
     from s4former_amd.presets import MAX_ITERS, OPTIMIZER, setr_pup_model, step_gflop, synthetic_batch
 
-    if os.environ.get('S4F_BENCH_WATCHDOG'):
-        import faulthandler                      # debugging aid: dump every thread's stack if the run stalls
-        faulthandler.dump_traceback_later(int(os.environ['S4F_BENCH_WATCHDOG']), repeat=False, exit=False)
+    wd = os.environ.get('S4F_BENCH_WATCHDOG', '300' if int(os.environ.get('WORLD_SIZE', '1')) > 1 else '')
+    if wd:
+        # a stalled rank dumps every thread's stack to a per-rank FILE (a captured pipe loses it) and EXITS non-zero, so
+        # that torchrun tears the peers down instead of waiting for them
+        import faulthandler
+        ddir = os.environ.get('S4F_WATCHDOG_DIR', os.path.join(ROOT, 'gpurun_out'))
+        os.makedirs(ddir, exist_ok=True)
+        global _WD_FILE
+        _WD_FILE = open(os.path.join(ddir, f"watchdog_rank{os.environ.get('RANK', '0')}.txt"), 'w')
+        faulthandler.dump_traceback_later(int(wd), repeat=False, file=_WD_FILE, exit=True)
     rank, local, world = init_distributed()
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)'
     assert torch.cuda.is_available(), 'bench.py needs a GPU (there is no CPU fallback on the product path)'
@@ -138,6 +150,7 @@ def main():
     S.set_compute_dtype(args.dtype)
 
     n_sup, n_unsup, img, ncls, flags, desc = WORKLOADS[args.workload]
+    bkw = dict(block=8, border=2) if args.workload == 'tiny' else {}
     torch.manual_seed(1999)                       # identical random-init weights on every rank
     model = S.build_segmentor(setr_pup_model(img=img, num_classes=ncls, **flags))
     model.init_weights()
@@ -146,36 +159,14 @@ def main():
     model.log_vars_as_tensors = True              # no host sync inside the step
     opt = S.build_optimizer(model, dict(OPTIMIZER))
     sched = S.PolyLR(opt, MAX_ITERS)
-    reducer = GradReducer()
 
-    batches = [synthetic_batch(1999 + 17 * rank + i, n_sup, n_unsup, img=img, num_classes=ncls, device=dev) for i in range(2)]
-    model.ensure_engine(dev)
-    reducer.broadcast_(model.student_store.flat)
-    if model.teacher_store is not None:
-        reducer.broadcast_(model.teacher_store.flat)
-    model.student_store.mark_dirty()
-    reducer.attach(model.student_store)
-    if world == 1 and os.environ.get('S4F_STREAM_LAYOUT', '').startswith('test'):
-        # rehearsal of the N > 1 stream layouts on one GPU: a stand-in for RCCL's stream is the first stream used (hardware
-        # queue 2) and runs a small kernel wherever SyncBN would all-reduce; 'test' = deliberate layout, 'test_lazy' = none
-        import s4former_amd.functional as F_
-        F_.STANDIN = torch.cuda.Stream(device=dev)
-        with torch.cuda.stream(F_.STANDIN):
-            torch.empty(1 << 20, device=dev).fill_(1.0)
-        if os.environ['S4F_STREAM_LAYOUT'] == 'test':
-            reducer._stream = F_.lay_out_streams(dev)
-    if world > 1 and os.environ.get('S4F_STREAM_LAYOUT', '1') != '0':
-        from s4former_amd.functional import lay_out_streams
-        reducer._stream = lay_out_streams(dev)      # collectives + eager SGD issue from the weight-gradient stream
-    if os.environ.get('S4F_EAGER_SGD', '1') != '0':
-        # parameter ranges are updated as soon as their (all-reduced) gradient is final, behind the rest of backward
-        rehearse = os.environ.get('S4F_STREAM_LAYOUT', '').startswith('test')
-        opt.attach_eager(model.student_store, reducer if (world > 1 or rehearse) else None, reducer.grad_scale())
+    batches = [synthetic_batch(1999 + 17 * rank + i, n_sup, n_unsup, img=img, num_classes=ncls, device=dev, **bkw) for i in range(2)]
+    reducer = setup_data_parallel(model, opt, dev)   # replicas made identical, per-range all-reduce + eager SGD hooked in
 
     seg_gain = 1.0
     if n_unsup:
         # every rank calibrates on the SAME batch (rank 0's): the teacher replicas stay bit-identical
-        calib = batches[0] if rank == 0 else synthetic_batch(1999, n_sup, n_unsup, img=img, num_classes=ncls, device=dev)
+        calib = batches[0] if rank == 0 else synthetic_batch(1999, n_sup, n_unsup, img=img, num_classes=ncls, device=dev, **bkw)
         seg_gain = calibrate_teacher(model, calib, n_sup, n_unsup, args.mask_ratio)
         del calib
 
@@ -287,7 +278,9 @@ def main():
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
                     config=dict(workload=f'{args.workload}: {desc}', images_per_step_per_gpu=n_sup + n_unsup,
                                 crop=f'{img}x{img}', classes=ncls, parallelism=f'dp{world}', weights='random-init DeiT-B',
-                                teacher_conv_seg_gain=round(seg_gain, 2)),
+                                teacher_conv_seg_gain=round(seg_gain, 2),
+                                dist_backend=dist.get_backend() if world > 1 else None,
+                                ranks_seen=dist.get_world_size() if world > 1 else 1),
                     roofline=roofline, cpu_baseline=cpu, losses=losses, mask_ratio=mask_ratio,
                     host_enqueue_ms_per_step=round(1e3 * host_dt / args.steps, 3))
         if kprof is not None:

@@ -6,30 +6,48 @@ all-reduces contiguous arena ranges (large buckets suit the point-to-point xGMI 
 as the last autograd node of the step has run, and the 1/world scaling is folded into the fused SGD kernel.
 SyncBN statistics (2*C floats per BN call) are all-reduced inside the head nodes (functional.py); the log
 scalars are reduced in one batched all-reduce (encoder_decoder.BaseSegmentor._parse_losses)."""
+import datetime
 import os
 
 import torch
 import torch.distributed as dist
 
+from ._lib import S4FError
 
-def init_distributed(backend=None):
-    """reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set by torch.distributed.run; returns (rank, local, world)"""
+
+def init_distributed(backend=None, timeout_s=None):
+    """reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set by torch.distributed.run; returns (rank, local, world).
+    timeout_s (or S4F_DIST_TIMEOUT_S, default 600): a collective that a peer never joins RAISES after that long instead of
+    hanging for the backends' 10 - 30 minute defaults."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get('S4F_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if timeout_s is None:
+            timeout_s = float(os.environ.get('S4F_DIST_TIMEOUT_S', '600'))
+        kw = {}
         if torch.cuda.is_available():
-            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
+            dev = local % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(dev)
+            if backend == 'nccl':
+                kw['device_id'] = torch.device('cuda', dev)     # eager communicator: no lazy init inside the first step
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return rank, local, world
 
 
 def world_size():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def collectives_active():
+    """True when the data path exchanges anything (N > 1).  tools/exp/rehearsal.py overrides this and the two issue()
+    hooks (GradReducer.issue, functional._Exchange.issue) to rehearse the N > 1 control flow on one GPU."""
+    return world_size() > 1
 
 
 class GradReducer:
@@ -74,22 +92,28 @@ class GradReducer:
                 self._stream.wait_stream(st)          # weight-gradient kernels / heads run on their own streams
         return torch.cuda.stream(self._stream)
 
+    @staticmethod
+    def issue(t):
+        """asynchronous sum-all-reduce of one arena range; returns the work handle"""
+        return dist.all_reduce(t, async_op=True)
+
     def _launch(self, t):
         with self._comm_ctx(t):
-            if _rehearsal() is not None:
-                self._handles.append(_StandInWork(t))
-            else:
-                self._handles.append(dist.all_reduce(t, async_op=True))
+            self._handles.append(self.issue(t))
 
     def _range_done(self, a, b):
-        if (world_size() == 1 and _rehearsal() is None) or self._store is None or self._store.grad is None:
+        if not collectives_active() or self._store is None or self._store.grad is None:
             return
+        if any(a < db and da < b for da, db in self._done):
+            raise S4FError(f'gradient range [{a}, {b}) was reported final twice in one step (a backward pass ran after the '
+                           'range had been handed to the reducer: gradient accumulation over several forward_train calls '
+                           'is not supported with an attached reducer)')
         self._launch(self._store.grad[a:b])
         self._done.append((a, b))
 
     def reduce_(self, flat_grad):
         """launch the all-reduces of every range not yet reduced in this step; call wait() before the optimiser step"""
-        if world_size() == 1 and _rehearsal() is None:
+        if not collectives_active():
             self._done = []
             return
         n = flat_grad.numel()
@@ -117,29 +141,33 @@ class GradReducer:
         return 1.0 / world_size()
 
 
-def _rehearsal():
-    """one-GPU rehearsal of the N > 1 control flow (bench.py, S4F_STREAM_LAYOUT=test): the stream standing in for RCCL's"""
-    if world_size() > 1:
-        return None
-    from . import functional as F_
-    return F_.STANDIN
+def setup_data_parallel(model, optimizer, device, reducer=None):
+    """What a training loop does ONCE after `model.to(device)` (bench.py and the world-2 tests share it):
+    build the arenas, make the replicas identical (broadcast of rank 0's student and teacher arenas), hook the gradient
+    reducer into the per-range `range_done` notifications and, unless S4F_EAGER_SGD=0, the optimiser's eager per-range step.
 
-
-class _StandInWork:
-    """what an asynchronous all-reduce does to the streams, without peers: RCCL's stream waits for the issuing stream, passes
-    over the buffer twice (a ring all-reduce reads and writes it about that often), and wait() makes the caller's stream
-    wait for it"""
-
-    def __init__(self, t):
-        st = _rehearsal()
-        st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st):
-            t.mul_(1.0)
-            t.mul_(1.0)
-        self._st = st
-
-    def wait(self):
-        torch.cuda.current_stream().wait_stream(self._st)
+    N > 1 defaults are the plain ones: per-range all-reduce on a communication stream during backward, the SGD of a range
+    behind its all-reduce.  The measured-on-one-GPU-only variants stay opt-in until they have run on RCCL:
+    S4F_STREAM_LAYOUT=1 (first-use order of the streams, functional.lay_out_streams), S4F_AUX_LOCKSTEP=1 /
+    S4F_DECODE_LOCKSTEP=1 (heads advancing in lockstep, one SyncBN exchange per layer for all of them).
+    Returns the reducer; per step:  backward -> join_side_streams() -> reducer.reduce_(store.grad) -> reducer.wait() ->
+    optimizer.step(grad_scale=reducer.grad_scale())."""
+    reducer = reducer if reducer is not None else GradReducer()
+    model.ensure_engine(device)
+    reducer.broadcast_(model.student_store.flat)
+    if model.teacher_store is not None:
+        reducer.broadcast_(model.teacher_store.flat)
+    model.student_store.mark_dirty()
+    if model.teacher_store is not None:
+        model.teacher_store.mark_dirty()
+    reducer.attach(model.student_store)
+    if collectives_active() and os.environ.get('S4F_STREAM_LAYOUT', '0') == '1':
+        from .functional import lay_out_streams
+        reducer._stream = lay_out_streams(device)      # collectives + eager SGD issue from the weight-gradient stream
+    if os.environ.get('S4F_EAGER_SGD', '1') != '0':
+        # parameter ranges are updated as soon as their (all-reduced) gradient is final, behind the rest of backward
+        optimizer.attach_eager(model.student_store, reducer if collectives_active() else None, reducer.grad_scale())
+    return reducer
 
 
 class _Null:

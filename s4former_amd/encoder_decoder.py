@@ -293,19 +293,14 @@ class EncoderDecoder(BaseSegmentor):
         return losses
 
     def _aux_lockstep(self):
-        mode = os.environ.get('S4F_AUX_LOCKSTEP', 'auto')
-        if mode == '0':
+        """S4F_AUX_LOCKSTEP=1 (opt-in until it has run on RCCL): the structurally identical auxiliary heads advance layer by
+        layer together, one SyncBN exchange per layer for all four (16 -> 4 per step).  Default: one head after the other,
+        the path every single-GPU parity test runs."""
+        if os.environ.get('S4F_AUX_LOCKSTEP', '0') != '1':
             return False
         heads = list(self.auxiliary_head)
-        same = len(heads) > 1 and all(hasattr(type(h), 'forward_train_lockstep') for h in heads) and \
+        return len(heads) > 1 and all(hasattr(type(h), 'forward_train_lockstep') for h in heads) and \
             len({(h.num_convs, h.channels, h.up_scale) for h in heads}) == 1
-        if not same:
-            return False
-        if mode == '1':
-            return True
-        from . import functional as F_
-        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        return distributed or F_.STANDIN is not None
 
     def _decode_lockstep(self):
         """S4F_DECODE_LOCKSTEP=1: the decode head's calls of a step advance in lockstep too (8 fewer SyncBN exchanges).  Off by

@@ -50,7 +50,9 @@ def head_stream(device, name, priority=0):
 
 
 def lay_out_streams(device):
-    """N > 1 only, after the first collective (RCCL's stream has then been USED first).  The runtime has FOUR hardware
+    """OPT-IN (S4F_STREAM_LAYOUT=1; dist.setup_data_parallel): inferred on one-GPU boxes with a stand-in for RCCL's stream
+    (tools/exp/queue_map.py, tools/exp/rehearsal.py), never measured with real RCCL streams.
+    N > 1 only, after the first collective (RCCL's stream has then been USED first).  The runtime has FOUR hardware
     queues; the default stream owns queue 1 and every other stream is bound at its first use, in the fixed pattern
     2 3 4 4 3 2 1 4 ... (tools/exp/queue_map.py); two streams on one queue serialise.  Wanted: the chain alone on queue 1,
     the decode / auxiliary head streams alone on queues 3 / 4, and the weight-gradient stream - which then also issues the
@@ -73,16 +75,6 @@ def lay_out_streams(device):
 
 
 _burn = []
-STANDIN = None                 # rehearsal of the N > 1 stream layout on one GPU: a stream standing in for RCCL's
-
-
-def _rehearse_allreduce(t):
-    """what a SyncBN all-reduce does to the queues: RCCL's stream waits for the caller's, runs a small kernel, the caller waits"""
-    cur = torch.cuda.current_stream()
-    STANDIN.wait_stream(cur)
-    with torch.cuda.stream(STANDIN):
-        t.add_(0.0)
-    cur.wait_stream(STANDIN)
 
 
 def extra_streams(device=None):
@@ -321,6 +313,7 @@ class LayerFn(Function):
         if any(ctx.needs_input_grad):
             ctx.store, ctx.prm = store, prm
             ctx.range = store.range_of(prm)
+            store.range_acquire(ctx.range)
             ctx.cfg = (Bn, N, E, F_, num_heads, bias_w)
             ctx.sv = dict(x=x, xn=xn, mean1=mean1, rstd1=rstd1, qkv=qkv, ctxv=ctxv, lse=lse, x1=x1, xn2=xn2, mean2=mean2,
                           rstd2=rstd2, z=z, a=a, bias_u=bias_u, row_flag=row_flag)
@@ -390,7 +383,7 @@ class LayerFn(Function):
         g0._s4f_colsum = (g0cs, g0._version, g0.data_ptr())
         ctx.sv = None
         store.node_done()
-        store.range_done(*ctx.range)
+        store.range_release(ctx.range)
         return (g0,) + (None,) * (6 + 12)
 
 
@@ -415,13 +408,16 @@ class _Exchange:
         self.i += 1
         return v
 
+    @staticmethod
+    def issue(buf):
+        """sum over the ranks, in place, ordered on the current stream"""
+        dist.all_reduce(buf)
+
     def reduce(self):
         if self.buf is None:
             return
         if self.world > 1:
-            dist.all_reduce(self.buf)
-        elif STANDIN is not None:
-            _rehearse_allreduce(self.buf)
+            self.issue(self.buf)
         self.buf = None
 
 
@@ -618,11 +614,8 @@ class HeadLossFn(Function):
             ctx.consumer = GRAD_CONSUMER
             # a head may be called several times per step (decode head: labelled + pseudo-labelled batch); its arena range
             # is final - and handed to the gradient reducer - when the last of those calls has run its backward
-            ep = getattr(store, 'step_epoch', 0)
-            if hp.get('_epoch') != ep:
-                hp['_epoch'], hp['_pending'] = ep, 0
-            hp['_pending'] += 1
             ctx.range = store.range_of(prm)
+            store.range_acquire(ctx.range)
         return (loss_sum * k).reshape(())
 
     @staticmethod
@@ -642,9 +635,7 @@ class HeadLossFn(Function):
             dtok.record_stream(ctx.consumer)          # allocated on the head's stream, read by the backbone's
         ctx.sv = None
         store.node_done()
-        hp['_pending'] = hp.get('_pending', 1) - 1
-        if hp['_pending'] == 0:
-            store.range_done(*ctx.range)
+        store.range_release(ctx.range)
         return (dtok, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
 
 
@@ -680,12 +671,9 @@ class MultiHeadLossFn(Function):
             k = float(lw) / float(Bn * H * W)
             losses.append((loss_sum * k).reshape(()))
             if need_grad:
-                ep = getattr(store, 'step_epoch', 0)
-                if hp.get('_epoch') != ep:
-                    hp['_epoch'], hp['_pending'] = ep, 0
-                hp['_pending'] += 1
-                saved.append(dict(sv=sv, hp=hp, meta=(k, Bn, h, w, s), lse=lse, labels=labels_u8,
-                                  range=store.range_of(tensors[off:off + nprm])))
+                rng = store.range_of(tensors[off:off + nprm])
+                store.range_acquire(rng)
+                saved.append(dict(sv=sv, hp=hp, meta=(k, Bn, h, w, s), lse=lse, labels=labels_u8, range=rng))
             off += nprm
         if need_grad:
             ctx.saved, ctx.store, ctx.n = saved, store, n
@@ -715,10 +703,7 @@ class MultiHeadLossFn(Function):
         for i in range(n):
             if ctx.consumer is not None:
                 dtoks[i].record_stream(ctx.consumer)
-            hp = ctx.saved[i]['hp']
             store.node_done()
-            hp['_pending'] = hp.get('_pending', 1) - 1
-            if hp['_pending'] == 0:
-                store.range_done(*ctx.saved[i]['range'])
+            store.range_release(ctx.saved[i]['range'])
         ctx.saved = None
         return (None, None) + tuple(dtoks) + (None,) * (len(ctx.needs_input_grad) - 2 - n)

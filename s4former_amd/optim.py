@@ -73,6 +73,9 @@ class S4FSGD(torch.optim.Optimizer):
     @torch.no_grad()
     def _range_done(self, a, b):
         store, reducer, scale = self._eager
+        if any(a < db and da < b for da, db, _ in self._eager_done):
+            raise S4FError(f'parameter range [{a}, {b}) was reported final twice before optimizer.step() (gradient '
+                           'accumulation over several backward passes needs S4F_EAGER_SGD=0)')
         handle = None
         if reducer is not None:
             n0 = len(reducer._handles)
@@ -147,6 +150,47 @@ class S4FSGD(torch.optim.Optimizer):
         if store.flat_t is not None and store._T_items:
             store.sync_T(eager=True)      # transposed operand shadows follow the bf16 shadow the SGD kernels just wrote
         return loss
+
+    # ------------------------------------------------------------------ checkpoint contents
+    # The reference's runner saves optimizer.state_dict() (mmcv CheckpointHook, save_optimizer=True): torch's layout
+    # {'state': {param index: {'momentum_buffer': tensor}}, 'param_groups': [...]}.  The momentum lives in the arena
+    # (ParamStore.mom), so the dict is assembled from / scattered into it here; a resumed run continues with its momentum.
+    def state_dict(self):
+        sd = super().state_dict()
+        store = self.model.student_store
+        if store is None or store.mom is None or store.first_sgd_step:
+            return sd
+        idx_of = {id(g['params'][0]): i for i, g in enumerate(self.param_groups)}
+        state = {}
+        for e in store.entries:
+            if not e.is_param:
+                continue
+            prm = e.module._parameters[e.attr]
+            if prm.requires_grad and id(prm) in idx_of:
+                state[idx_of[id(prm)]] = {'momentum_buffer': store._view(store.mom, e).detach().clone()}
+        sd['state'] = state
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state = state_dict.get('state', {})
+        super().load_state_dict(dict(state_dict, state={}))
+        self._plan_cache = None
+        if not state:
+            return
+        store = self.model.student_store
+        if store is None or store.mom is None:
+            raise S4FError('optimizer.load_state_dict() with momentum buffers needs the arenas: call '
+                           'model.ensure_engine(device) (or run one forward) first')
+        by_idx = {i: g['params'][0] for i, g in enumerate(self.param_groups)}
+        with torch.no_grad():
+            store.mom.zero_()
+            for k, st in state.items():
+                buf = st.get('momentum_buffer') if isinstance(st, dict) else None
+                if buf is None:
+                    continue
+                e = store.entry(by_idx[int(k)])
+                store._view(store.mom, e).copy_(buf.to(store.mom.device))
+        store.first_sgd_step = False
 
     def zero_grad(self, set_to_none=False):
         store = self.model.student_store

@@ -272,11 +272,31 @@ class ParamStore:
         return a, b
 
     def range_done(self, a, b):
-        """the gradients of arena range [a, b) are final for this step (called at the end of a node's backward);
-        the data-parallel reducer hooks in here to start that bucket's all-reduce while backward continues"""
+        """the gradients of arena range [a, b) are final for this step; the data-parallel reducer / the eager optimiser
+        hook in here to start that bucket's all-reduce / update while backward continues"""
         cb = getattr(self, 'on_range_done', None)
         if cb is not None:
             cb(a, b)
+
+    # A range is FINAL when the last node that accumulates into it has run its backward.  A node announces itself in its
+    # forward (range_acquire) and signs off at the end of its backward (range_release); the counts restart with every step
+    # (step_epoch, bumped by the segmentor).  A layer used by two passes of one step (masked + plain student pass, gradient
+    # accumulation) is therefore reported once, after the second backward.  A graph that is never run backward leaves its
+    # count above zero: the range is then simply not reported early and falls to reduce_() / step(), which cover the rest.
+    def range_acquire(self, rng):
+        ep = getattr(self, 'step_epoch', 0)
+        if getattr(self, '_pend_epoch', None) != ep:
+            self._pend, self._pend_epoch = {}, ep
+        self._pend[rng] = self._pend.get(rng, 0) + 1
+
+    def range_release(self, rng):
+        pend = getattr(self, '_pend', None)
+        if pend is None or rng not in pend:
+            return
+        pend[rng] -= 1
+        if pend[rng] == 0:
+            del pend[rng]
+            self.range_done(*rng)
 
     def zero_grad(self):
         if self.grad is not None:

@@ -1,0 +1,135 @@
+"""N > 1 path on ONE GPU: two ranks over gloo (RCCL needs one GPU per rank; the collectives, the SyncBN statistics
+exchange, the per-range gradient all-reduce during backward, the eager SGD behind it and the rank-0-only reporting are the
+same code).  Runs LAST (file name) and on the TINY model with hard time caps: a multi-process test must never gate the
+kernel-parity tests.  A stalled rank dumps its stacks to a file and exits; the dumps are printed on failure.
+
+Asserted (reference mmseg/apis/train.py:129-138, segmentors/base.py:257-272):
+  * 2-rank losses (mean over ranks) == 1-rank losses of the concatenated global batch   (SyncBN == BN over the concatenation)
+  * state after two steps (weights, BN running statistics, EMA teacher) == the 1-rank run's
+  * replicas bit-identical: student arena, SGD momentum arena, teacher arena
+for the default N > 1 path and for the opt-in variants (lockstep heads, stream layout, no eager SGD)."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(ROOT, 'tests', 'dist_worker.py')
+CAP = 120          # seconds per launched job
+
+
+def _dumps(d):
+    out = []
+    for f in sorted(glob.glob(os.path.join(d, 'watchdog_rank*.txt'))):
+        txt = open(f).read()
+        if txt.strip():
+            out.append(f'---- {os.path.basename(f)}\n{txt[-6000:]}')
+    return '\n'.join(out)
+
+
+def _run(cmd, env, out_dir):
+    try:
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=CAP)
+    except subprocess.TimeoutExpired as e:
+        so = (e.stdout or b'').decode(errors='replace') if isinstance(e.stdout, bytes) else (e.stdout or '')
+        se = (e.stderr or b'').decode(errors='replace') if isinstance(e.stderr, bytes) else (e.stderr or '')
+        pytest.fail(f'timed out after {CAP} s: {" ".join(cmd[-8:])}\n{so[-2000:]}\n{se[-4000:]}\n{_dumps(out_dir)}')
+    assert r.returncode == 0, f'rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}\n{_dumps(out_dir)}'
+    return r
+
+
+def _torchrun(nproc, port, script_args):
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr',
+            '127.0.0.1', '--master-port', str(port)] + script_args
+
+
+def _env(**extra):
+    env = dict(os.environ, S4F_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0', S4F_AUTOTUNE='0')
+    env.update(extra)
+    return env
+
+
+def _load(d, rank):
+    z = np.load(os.path.join(d, f'rank{rank}.npz'), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(scope='module')
+def single(tmp_path_factory):
+    """the expected result: the whole global batch in ONE process (fp32 parity mode), per flag set"""
+    res = {}
+    for flags in ('pasa', 'plain'):
+        d = str(tmp_path_factory.mktemp(f'w1_{flags}'))
+        _run([sys.executable, WORKER, '--out', d, '--flags', flags], _env(), d)
+        res[flags] = _load(d, 0)
+    return res
+
+
+VARIANTS = {
+    'default': {},
+    'no_eager_sgd': dict(S4F_EAGER_SGD='0'),
+    'lockstep_heads': dict(S4F_AUX_LOCKSTEP='1', S4F_DECODE_LOCKSTEP='1'),
+    'stream_layout': dict(S4F_STREAM_LAYOUT='1'),
+}
+
+
+@pytest.mark.parametrize('variant,flags', [('default', 'pasa'), ('default', 'plain'), ('no_eager_sgd', 'pasa'),
+                                           ('lockstep_heads', 'pasa'), ('stream_layout', 'plain')])
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(variant, flags, single, tmp_path):
+    d = str(tmp_path)
+    port = 29600 + sorted(VARIANTS).index(variant) * 2 + (flags == 'plain')
+    _run(_torchrun(2, port, [WORKER, '--out', d, '--flags', flags]), _env(**VARIANTS[variant]), d)
+    r0, r1, ref = _load(d, 0), _load(d, 1), single[flags]
+    assert json.loads(str(r0['meta']))['world'] == 2
+    # replicas bit-identical after two steps
+    for k in ('student_sha', 'mom_sha', 'teacher_sha'):
+        assert str(r0[k]) == str(r1[k]), f'{k} differs between the ranks'
+    msgs = []
+    for it in range(2):
+        keys = [str(k) for k in ref[f'it{it}_loss_keys']]
+        assert [str(k) for k in r0[f'it{it}_loss_keys']] == keys
+        # logged values are already the mean over the ranks (batched all-reduce of _parse_losses): identical on both ranks
+        assert np.array_equal(r0[f'it{it}_loss_vals'], r1[f'it{it}_loss_vals'])
+        for k, got, want in zip(keys, r0[f'it{it}_loss_vals'], ref[f'it{it}_loss_vals']):
+            if abs(got - want) > 1e-5 * abs(want) + 1e-7:
+                msgs.append(f'it{it} {k}: 2 ranks {got:.7f} vs 1 rank {want:.7f}')
+        # the loss backward runs on stays local; its rank mean is the logged total
+        lm = 0.5 * (float(r0[f'it{it}_local_loss']) + float(r1[f'it{it}_local_loss']))
+        tot = float(r0[f'it{it}_loss_vals'][keys.index('loss')])
+        assert abs(lm - tot) <= 1e-6 * abs(tot)
+    # state after two optimiser steps: weights, BN running statistics (SyncBN == BN of the concatenated batch), EMA teacher
+    assert [str(k) for k in r0['state_keys']] == [str(k) for k in ref['state_keys']]
+    for k, got, want, gs, ws in zip(ref['state_keys'], r0['state_abs_sum'], ref['state_abs_sum'], r0['state_sum'], ref['state_sum']):
+        if abs(got - want) > 2e-5 * abs(want) + 1e-7 or abs(gs - ws) > 2e-5 * abs(want) + 1e-6:
+            msgs.append(f'state {k}: |.|_1 {got:.7f} vs {want:.7f}, sum {gs:.7f} vs {ws:.7f}')
+    assert np.array_equal(r0['nbt'], ref['nbt'])
+    assert not msgs, '\n'.join(msgs[:20])
+
+
+def test_two_ranks_bf16_replicas_stay_identical(tmp_path):
+    """perf mode through the same path: finite losses, replicas bit-identical"""
+    d = str(tmp_path)
+    _run(_torchrun(2, 29620, [WORKER, '--out', d, '--flags', 'plain', '--dtype', 'bf16']), _env(), d)
+    r0, r1 = _load(d, 0), _load(d, 1)
+    for k in ('student_sha', 'mom_sha', 'teacher_sha'):
+        assert str(r0[k]) == str(r1[k]), f'{k} differs between the ranks'
+    assert np.all(np.isfinite(r0['it1_loss_vals']))
+
+
+def test_bench_two_ranks_gloo(tmp_path):
+    """bench.py's own N > 1 control flow (rank-symmetric profiled step, rank-0-only reporting, barriers) on the tiny workload"""
+    d = str(tmp_path)
+    env = _env(S4F_BENCH_WATCHDOG='90', S4F_WATCHDOG_DIR=d, S4F_DIST_TIMEOUT_S='60')
+    r = _run(_torchrun(2, 29630, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                                  '--workload', 'tiny', '--no-cpu-baseline']), env, d)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['roofline'] is not None
+    assert out['config']['dist_backend'] == 'gloo' and out['config']['ranks_seen'] == 2
+    assert abs(out['losses']['loss']) < 1e3
