@@ -4,8 +4,9 @@ CPU restatement, in plain torch fp32, of the arithmetic of every op on the S4For
 cites the reference file:line it follows (paths relative to the reference repo JoyHuYY1412/S4Former).  Only
 tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 
-Parity status: pinned (a) by the reference's own known-answer CE tests (tests/golden/ce_known_answers.json,
-from reference tests/test_models/test_losses/test_ce_loss.py) and (b) by golden vectors generated in the build
+Parity status: pinned (a) by the reference's own known-answer CE tests (the answers of reference
+tests/test_models/test_losses/test_ce_loss.py, restated inline in tests/test_oracle_golden.py::test_reference_ce_known_answers
+and tests/test_kernels_gpu.py::test_ce_known_answers) and (b) by golden vectors generated in the build
 container from the reference's own hot-path files imported under a minimal mmcv stand-in
 (tests/golden/make_golden.py -> tests/golden/*.npz).
 """

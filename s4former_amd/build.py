@@ -13,16 +13,15 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 OBJ_DIR = os.path.join(CSRC, '_obj')
 LIB_PATH = os.path.join(PKG_DIR, 'libs4f_hip.so')
-SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm3.hip', 'gemm4.hip', 'gemm5.hip', 'gemm6.hip', 'attention.hip', 'elementwise.hip', 'head.hip']
+SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm5.hip', 'gemm6.hip', 'attention.hip', 'elementwise.hip', 'head.hip']
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 's4f.h')]
 BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off',
               '-Wno-unused-result', '-Wno-unused-value']
 FLAGS = BASE_FLAGS + ['-mllvm', '-amdgpu-mfma-vgpr-form=1']
-# per-file overrides: gemm4.hip keeps its 256 accumulators per lane in AGPRs (no vgpr-form); it #includes gemm2.hip
-FILE_FLAGS = {'gemm4.hip': BASE_FLAGS}
+FILE_FLAGS = {}      # per-file overrides
 if os.environ.get('S4F_G5_PROBES'):
     FILE_FLAGS['gemm5.hip'] = FLAGS + ['-DG5_PROBES']
-FILE_DEPS = {'gemm4.hip': ['gemm2.hip'], 'gemm5.hip': ['gemm2.hip'], 'gemm6.hip': ['gemm2.hip']}
+FILE_DEPS = {'gemm5.hip': ['gemm2.hip'], 'gemm6.hip': ['gemm2.hip']}
 
 
 def _hipcc():

@@ -323,8 +323,6 @@ int dispatch(const s4f_gemm_desc& d, hipStream_t st) {
 }  // namespace
 
 int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn);   // gemm2.hip
-int s4f_gemm4_try(const s4f_gemm_desc& d, hipStream_t st);
-int s4f_gemm3_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm3.hip
 int s4f_gemm5_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm5.hip
 int s4f_gemm6_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm6.hip
 int s4f_gemm6_grouped_try(const s4f_gemm_desc* ds, int count, hipStream_t st);
@@ -335,8 +333,6 @@ static int pick_tile(const s4f_gemm_desc& d) {
   if (d.tile_hint == 1) return 0;
   if (d.tile_hint == 2) return 128;
   if (d.tile_hint == 3 || d.tile_hint == 4) return 256;
-  if (d.tile_hint == 5 || d.tile_hint == 6) return 512;
-  if (d.tile_hint == 7) return 1024;
   if (d.tile_hint >= 10 && d.tile_hint <= 12) return 2048;                       // 8-wave ping-pong kernel (gemm5.hip)
   if (d.tile_hint == 8 || d.tile_hint == 9) return 192;     // 256 x 192 tile, 16 / 8 waves (token GEMMs with N = 768, 2304)
   const long sk = d.splitk < 1 ? 1 : d.splitk;
@@ -384,9 +380,7 @@ S4F_API int s4f_gemm(const s4f_gemm_desc* dp, s4f_stream stream) {
   }
   const int bn = pick_tile(d);
   int rc = -100;
-  if (bn == 512) rc = s4f_gemm3_try(d, (hipStream_t)stream);
-  else if (bn == 1024) rc = s4f_gemm4_try(d, (hipStream_t)stream);
-  else if (bn == 2048) rc = d.a_mode == S4F_OP_K ? s4f_gemm6_try(d, (hipStream_t)stream) : s4f_gemm5_try(d, (hipStream_t)stream);
+  if (bn == 2048) rc = d.a_mode == S4F_OP_K ? s4f_gemm6_try(d, (hipStream_t)stream) : s4f_gemm5_try(d, (hipStream_t)stream);
   else if (bn) rc = s4f_gemm2_try(d, (hipStream_t)stream, bn);
   if (rc == -100) rc = d.dtype == S4F_BF16 ? dispatch<bf16_t>(d, (hipStream_t)stream) : dispatch<float>(d, (hipStream_t)stream);
   if (rc == -100) S4F_FAIL(-2, "s4f_gemm: unsupported operand mode pair (%d, %d)", d.a_mode, d.b_mode);

@@ -123,6 +123,7 @@ class SETRUPHead(BaseDecodeHead):
         self._store = None
         self._store_owner = False
         self._register_state_dict_hook(SETRUPHead._sd_hook)
+        self._register_load_state_dict_pre_hook(self._load_hook)
 
     # num_batches_tracked is counted on the host (no per-call device op) and materialised on state_dict()
     @staticmethod
@@ -132,6 +133,12 @@ class SETRUPHead(BaseDecodeHead):
             if key in state_dict:
                 state_dict[key] = state_dict[key] + c[0]
         return state_dict
+
+    def _load_hook(self, state_dict, prefix, *args):
+        """a loaded num_batches_tracked already contains what the host counters held when it was saved"""
+        for k, c in enumerate(self._nbt):
+            if f'{prefix}up_convs.{k}.0.bn.num_batches_tracked' in state_dict:
+                c[0] = 0
 
     # ------------------------------------------------------------------ store plumbing
     def _attach_store(self, store):

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import runtime
-from ._lib import S4FError
+from ._lib import F32, S4FError
 from .base_module import BaseModule, ModuleList, constant_init, kaiming_init, trunc_normal_
 from .functional import LayerFn, PatchEmbedFn
 from .params import ParamStore
@@ -210,6 +210,10 @@ class VisionTransformer(BaseModule):
             self.load_state_dict(state_dict, strict=False)
             return
         if isinstance(self.init_cfg, dict) and self.init_cfg.get('type') == 'Pretrained':
+            # the reference raises in CheckpointLoader.load_checkpoint; a silent random initialisation of student and teacher
+            # behind a mistyped path is not an option (init_cfg allow_missing=True asks for it explicitly)
+            if not self.init_cfg.get('allow_missing', False):
+                raise FileNotFoundError(f'init_cfg checkpoint {ck!r} does not exist')
             warnings.warn(f'checkpoint {ck!r} not found: falling back to the random (jax_impl) initialisation')
         # vit.py:396-414
         trunc_normal_(self.pos_embed, std=.02)
@@ -268,7 +272,16 @@ class VisionTransformer(BaseModule):
         flag = None
         if adaptive_attn_mask:
             # if the patch is more confident than half (<half), it is not encouraged to change
-            idx = torch.topk(u[:, 1:], int(0.5 * (u.size(-1) - 1)), dim=-1, largest=False)[1] + 1
+            # u takes the values k / 256: the k-th smallest is often TIED with its neighbours, and which of the tied patches
+            # torch.topk returns is implementation-defined (CPU: libstdc++ nth_element; GPU: radix select).  fp32 parity mode
+            # (and S4F_TOPK_TIES=cpu) takes the reference CPU path's choice by running the selection on the host: a 4 KB
+            # round trip and a host sync per step, so the bf16 perf mode keeps the device selection (S4F_TOPK_TIES=device).
+            k = int(0.5 * (u.size(-1) - 1))
+            ties = os.environ.get('S4F_TOPK_TIES') or ('cpu' if runtime.compute_dtype() == F32 else 'device')
+            if ties == 'cpu':
+                idx = (torch.topk(u[:, 1:].cpu(), k, dim=-1, largest=False)[1] + 1).to(u.device)
+            else:
+                idx = torch.topk(u[:, 1:], k, dim=-1, largest=False)[1] + 1
             flag = torch.ones_like(u)
             flag[torch.arange(B, device=u.device).unsqueeze(1), idx] = 0
         return u, flag, float(attn_mask_weight)

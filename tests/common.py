@@ -120,3 +120,59 @@ def grad_norms(model, prefix_filter=None):
         if p.grad is not None and (prefix_filter is None or n.startswith(prefix_filter)):
             out[n] = float(p.grad.detach().float().norm())
     return out
+
+
+NS = 64
+
+
+def grad_sample(g, ns=NS):
+    """ns elements of the flattened LOGICAL (torch-layout) tensor at a fixed stride: the rule tests/golden/make_golden*.py
+    used on the reference's gradients"""
+    f = g.detach().reshape(-1)
+    step = max(1, f.numel() // ns)
+    return f[::step][:ns]
+
+
+def check_grad_samples(z, it, named_grads, tol, msgs, label=''):
+    """Element-wise comparison of EVERY parameter's gradient with the golden samples, relative to the tensor's largest element.
+
+    Iteration 0 is held against the reference's FLOAT64 evaluation of the same step (`it0_gs64`): |got - ref64| <= max(tol, 8 D)
+    where D is the distance of the reference's OWN fp32 gradients from that fp64 evaluation (worst tensor).  On the tiny fixtures
+    (batch seeds without ReLU ties, make_golden.relu_margin) D ~ 2e-6 and the bound is `tol` itself (1e-4 in fp32 mode); at
+    DeiT-B size the reference's fp32 gradients are themselves only good to D ~ 5e-3 (tens of ReLU decisions within rounding of
+    zero flip between fp32 and fp64), and no implementation can be closer to the reference than the reference is to itself.
+    The median over tensors must stay within max(tol / 10, 4 median D).  Later iterations: against the fp32 samples."""
+    keys = [str(k) for k in z[f'it{it}_gn_keys']]
+    gs, gmax = z[f'it{it}_gs'], z[f'it{it}_gmax']
+    ref, D, Dmed = gs, 0.0, 0.0
+    if it == 0 and 'it0_gs64' in z.files:
+        ref = z['it0_gs64']
+        d = np.abs(gs.astype(np.float64) - ref).max(axis=1) / (gmax + 1e-30)
+        D, Dmed = float(d.max()), float(np.median(d))
+    errs = []
+    for i, k in enumerate(keys):
+        got = grad_sample(named_grads[k], gs.shape[1]).double().cpu().numpy()
+        errs.append(float(np.abs(got - ref[i, :got.size]).max()) / (float(gmax[i]) + 1e-30))
+    w = int(np.argmax(errs))
+    bound, mbound = max(tol, 8 * D), max(tol / 10, 4 * Dmed)
+    if errs[w] > bound:
+        msgs.append(f'{label}it{it} gradient elements of {keys[w]}: {errs[w]:.2e} of the tensor maximum (bound {bound:.1e}; the '
+                    f"reference's own fp32 is {D:.1e} from its fp64 evaluation)")
+    if float(np.median(errs)) > mbound:
+        msgs.append(f'{label}it{it} gradient elements, median over tensors: {float(np.median(errs)):.2e} (bound {mbound:.1e})')
+    return errs[w], keys[w], float(np.median(errs)), D
+
+
+def fragile_pixels(z, logit_tol, th=0.95):
+    """pixels whose pseudo-label decision the REFERENCE's own arithmetic makes by less than the stated bound: a top-2 logit
+    margin below logit_tol (argmax may flip) or a softmax maximum within the band around the threshold that a logit
+    perturbation of logit_tol can move it by (|dp| <= p (1 - p) * 2 * logit_tol <= logit_tol / 2; confidence may flip)"""
+    if 'teacher_margin_final' in z.files:
+        margin, pmax = z['teacher_margin_final'], z['teacher_pmax_final']
+        return (margin < logit_tol) | (np.abs(pmax - th) < 0.5 * logit_tol + 1e-7)
+    # full-size goldens store the candidates only (every pixel within `frag` * max |logit|): sparse index + values
+    shape = z['teacher_label_final'].shape
+    idx, margin, pmax = z['teacher_frag_idx'], z['teacher_frag_margin'], z['teacher_frag_pmax']
+    out = np.zeros(int(np.prod(shape)), dtype=bool)
+    out[idx] = (margin < logit_tol) | (np.abs(pmax - th) < 0.5 * logit_tol + 1e-7)
+    return out.reshape(shape)

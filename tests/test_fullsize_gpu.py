@@ -28,7 +28,8 @@ def _one_step(dtype, gain, n_sup, n_unsup, img, ncls):
     dev = torch.device('cuda', 0)
     S.set_compute_dtype(dtype)
     torch.manual_seed(1999)
-    model = S.build_segmentor(setr_pup_model(img=img, num_classes=ncls, unsup_weight=1.0, plain_mt_pseudo_loss=True))
+    flags = dict(unsup_weight=1.0, plain_mt_pseudo_loss=True) if n_unsup else dict(unsup_weight=0)
+    model = S.build_segmentor(setr_pup_model(img=img, num_classes=ncls, **flags))
     model.init_weights()
     model.train()
     model.to(dev)
@@ -38,7 +39,9 @@ def _one_step(dtype, gain, n_sup, n_unsup, img, ncls):
     batch = synthetic_batch(1999, n_sup, n_unsup, img=img, num_classes=ncls, device=dev)
     model.ensure_engine(dev)
     model.student_store.mark_dirty()
-    if gain is None:
+    if not n_unsup:
+        gain = 1.0
+    elif gain is None:
         gain = bench.calibrate_teacher(model, batch, n_sup, n_unsup, 0.5)
     else:
         with torch.no_grad():
@@ -56,7 +59,7 @@ def _one_step(dtype, gain, n_sup, n_unsup, img, ncls):
     torch.cuda.synchronize()
     res = dict(gain=gain,
                losses={k: float(v) for k, v in out['log_vars'].items()},
-               mask_ratio=float(model.last_mask_ratio),
+               mask_ratio=float(model.last_mask_ratio) if n_unsup else None,
                grad=model.student_store.grad.clone(),
                teacher0=teacher0, student0=student0,
                teacher1=model.teacher_store.flat.clone(),
@@ -69,7 +72,7 @@ def _one_step(dtype, gain, n_sup, n_unsup, img, ncls):
     return res
 
 
-@pytest.fixture(scope='module', params=[(8, 8, 512, 21), (4, 4, 768, 19)], ids=['cfg3_512', 'cfg5_768'])
+@pytest.fixture(scope='module', params=[(8, 0, 512, 21), (8, 8, 512, 21), (4, 4, 768, 19)], ids=['cfg2_sup8', 'cfg3_512', 'cfg5_768'])
 def runs(request):
     import s4former_amd as S
     try:
@@ -85,8 +88,9 @@ def test_bf16_step_agrees_with_fp32_step(runs):
     assert set(f32['losses']) == set(bf16['losses'])
     for k, v in f32['losses'].items():
         assert abs(bf16['losses'][k] - v) <= 2e-2 * abs(v) + 1e-3, (k, v, bf16['losses'][k])
-    assert 0.3 < f32['mask_ratio'] < 0.7                       # the pseudo-label path is not degenerate
-    assert abs(bf16['mask_ratio'] - f32['mask_ratio']) < 0.02
+    if f32['mask_ratio'] is not None:
+        assert 0.3 < f32['mask_ratio'] < 0.7                       # the pseudo-label path is not degenerate
+        assert abs(bf16['mask_ratio'] - f32['mask_ratio']) < 0.02
     g0, g1 = f32['grad'].double(), bf16['grad'].double()
     assert torch.isfinite(g1).all()
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
@@ -115,3 +119,123 @@ def test_first_sgd_step_moves_against_the_gradient(runs, which):
     # (an update below half an ulp of the parameter leaves it unchanged: only the moved ones are checked)
     assert float(moved.double().mean()) > 0.5
     assert bool((d[moved] * g[moved] < 0).all())
+
+
+# ------------------------------------------------------------------------------------------------ goldens from the reference
+# Full-size goldens made in the build container FROM THE REFERENCE'S OWN CODE (tests/golden/make_golden_full.py): DeiT-B /
+# SETR-PUP 512x512 (2 labelled images = cfg1 / cfg2 shapes; 2 + 2 with PASA = cfg3 / cfg4 shapes), two iterations, and one
+# 768x768 / 19-class / 2305-token forward (cfg5 shapes).  Both numeric modes are held against them at the PRODUCTION kernel
+# variants (shipped tuning table): fp32 parity mode at north_star's 1e-4, bf16 perf mode at its stated bf16 bounds.
+import json  # noqa: E402
+
+import numpy as np  # noqa: E402
+
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+TOL = {   # (loss it0, loss it1, grad-norm it0, it1, grad-element it0, it1, final |.|_1, logit bound for the tie set)
+    'fp32': (1e-4, 1e-3, 2e-3, 5e-3, 1e-4, 5e-2, 2e-4, 2e-5),
+    'bf16': (2e-2, 4e-2, 8e-2, 1.5e-1, 5e-1, 5e-1, 2e-2, 2e-2),
+}
+
+
+def _golden_run(name, dtype):
+    import s4former_amd as S
+    from tests import common as C
+    z = np.load(os.path.join(GOLD, f'{name}.npz'), allow_pickle=False)
+    meta = json.loads(str(z['meta']))
+    S.set_compute_dtype(dtype)
+    model = S.build_segmentor(C.deit_b_cfg(img=meta['img'], num_classes=meta['num_classes'], **meta['flags']))
+    model.train()
+    C.load_filled(model, meta['seed_w'], meta['gain'])
+    model.cuda()
+    opt = S.build_optimizer(model, dict(type='SGD', lr=meta['lr'], momentum=0.9, weight_decay=0.0,
+                                        paramwise_cfg=dict(custom_keys={'head': dict(lr_mult=10.)})))
+    sched = S.PolyLR(opt, 80001)
+    rec = []
+    bkw = dict(img=meta['img'], num_classes=meta['num_classes'], block=32, border=8)
+    for it in range(max(1, meta['iters'])):
+        imgs, gt, metas = C.make_batch(meta['seed_b'] + it, meta['n_sup'], meta['n_unsup'], **bkw)
+        assert C.sha(imgs) == meta['input_sha'][it], 'deterministic input generator drifted'
+        sched.step(it)
+        opt.zero_grad()
+        out = model.train_step(dict(img=imgs.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda()), opt, iter=it)
+        r = dict(log=out['log_vars'])
+        if meta['iters']:
+            out['loss'].backward()
+            torch.cuda.synchronize()
+            named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None]
+            r['gn'] = {n: float(p.grad.norm()) for n, p in named}
+            r['g'] = {n: C.grad_sample(p.grad, meta['ns']).clone() for n, p in named}
+            opt.step()
+        rec.append(r)
+    torch.cuda.synchronize()
+    info = None
+    if meta['n_unsup']:
+        imgs, gt, metas = C.make_batch(meta['seed_b'] + max(1, meta['iters']) - 1, meta['n_sup'], meta['n_unsup'], **bkw)
+        n0 = meta['n_sup'] + meta['n_unsup']
+        with torch.no_grad():
+            model.set_eval(True)
+            t = model.extract_teacher_info_ema(imgs[n0:].cuda(), metas[n0:])
+            model.set_train(True)
+        info = dict(label=t['hard_seg_label'].cpu().numpy(), ratio=float(t['conf_count']) / t['hard_seg_label'].numel())
+    sd = {k: float(v.double().abs().sum()) for k, v in model.state_dict().items() if v.dtype.is_floating_point}
+    del model, opt
+    torch.cuda.empty_cache()
+    return z, meta, rec, info, sd
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('name', ['full_sup', 'full_pasa', 'full_768'])
+def test_fullsize_step_vs_reference_golden(name, dtype):
+    import s4former_amd as S
+    from tests import common as C
+    try:
+        z, meta, rec, info, sd = _golden_run(name, dtype)
+    finally:
+        S.set_compute_dtype('fp32')
+    tl0, tl1, tg0, tg1, te0, te1, tw, tz = TOL[dtype]
+    msgs = []
+    for it in range(max(1, meta['iters'])):
+        keys = [str(k) for k in z[f'it{it}_loss_keys']]
+        assert sorted(k for k in keys if 'loss' in k) == sorted(k for k in rec[it]['log'] if 'loss' in k and k != 'loss')
+        for k, v in zip(keys, z[f'it{it}_loss_vals']):
+            if 'loss' in k:
+                e = abs(rec[it]['log'][k] - v) / abs(v)
+                if e > (tl0, tl1)[it]:
+                    msgs.append(f'it{it} {k}: {rec[it]["log"][k]:.6f} vs {v:.6f} (rel {e:.2e})')
+        e = abs(rec[it]['log']['loss'] - float(z[f'it{it}_loss'])) / abs(float(z[f'it{it}_loss']))
+        if e > (tl0, tl1)[it]:
+            msgs.append(f'it{it} total loss rel {e:.2e}')
+        if not meta['iters']:
+            continue
+        gk = [str(k) for k in z[f'it{it}_gn_keys']]
+        assert sorted(gk) == sorted(rec[it]['gn']), set(gk) ^ set(rec[it]['gn'])
+        worst = max(((abs(rec[it]['gn'][k] - v) / (abs(v) + 1e-12), k) for k, v in zip(gk, z[f'it{it}_gn_vals'])))
+        if worst[0] > (tg0, tg1)[it]:
+            msgs.append(f'it{it} grad norm {worst[1]}: rel {worst[0]:.2e}')
+        w = C.check_grad_samples(z, it, rec[it]['g'], (te0, te1)[it], msgs)
+        print(f'{name} {dtype} it{it}: worst grad norm {worst[0]:.2e} ({worst[1]}), grad elements: worst {w[0]:.2e} ({w[1]}), median '
+              f'{w[2]:.2e}; reference fp32 vs its fp64: {w[3]:.2e}')
+    for k, ref in zip(z['final_sha_keys'], z['final_abs_sum']):
+        got = sd[str(k)]
+        if abs(got - ref) > tw * abs(ref) + 1e-9:
+            msgs.append(f'final |{k}|_1: {got:.6f} vs {ref:.6f}')
+    if info is not None:
+        ref = z['teacher_label_final']
+        mism = info['label'] != ref
+        if dtype == 'fp32':
+            tol = tz * float(z['teacher_logit_absmax_final'])
+            fragile = C.fragile_pixels(z, tol)
+            bad = mism & ~fragile
+            print(f'{name} fp32 labels: {int(mism.sum())} of {ref.size} differ, {int(fragile.sum())} ties within {tol:.2e}, '
+                  f'{int(bad.sum())} outside the tie set')
+            if bad.any():
+                msgs.append(f'{int(bad.sum())} pseudo-label pixels differ outside the tie set')
+            if float(fragile.mean()) > 0.01:
+                msgs.append('tie set is not a small minority')
+        else:
+            print(f'{name} bf16 labels: {float(mism.mean()):.3%} differ')
+            if float(mism.mean()) > 0.05:
+                msgs.append(f'{float(mism.mean()):.2%} of the bf16 pseudo-labels differ from the reference')
+        if abs(info['ratio'] - float(z['teacher_mask_ratio_final'])) > (2e-3 if dtype == 'fp32' else 3e-2):
+            msgs.append(f'mask ratio {info["ratio"]:.4f} vs {float(z["teacher_mask_ratio_final"]):.4f}')
+    assert not msgs, '\n'.join(msgs[:20])

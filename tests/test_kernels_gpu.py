@@ -498,7 +498,7 @@ def test_ema_sgd(K, code):
 
 
 # ------------------------------------------------------------------------------------------------ 256-row LDS-DMA kernel
-@pytest.mark.parametrize('hint', [2, 3, 4, 5, 6, 7, 8, 9, 10])
+@pytest.mark.parametrize('hint', [2, 3, 4, 8, 9, 10])
 def test_gemm2_dense_modes(K, hint):
     code = 1
     M, N, K_ = 1000, 768, 832
@@ -535,7 +535,7 @@ def test_gemm2_dense_modes(K, hint):
     assert float(o21[:, 21:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('hint', [3, 4, 7, 8, 9, 10])
+@pytest.mark.parametrize('hint', [3, 4, 8, 9, 10])
 @pytest.mark.parametrize('M', [2 * 1025, 2 * 1025 + 6, 512 + 16, 256 + 1, 256 + 17, 255])
 def test_gemm2_folded_tail(K, hint, M):
     """token GEMMs have M = B * 1025: a row remainder <= 16 is folded into the last tile row (hints 3/4/8/9), 17 is not;
@@ -565,7 +565,7 @@ def test_gemm2_folded_tail(K, hint, M):
     gp = q(torch.rand(M, K2, generator=torch.Generator().manual_seed(7)) * 1.2 - 0.1, code)
     dz = torch.empty(M, K2, device='cuda', dtype=tdt(code))
     K.gemm(dev(dy, code), dev(w2, code), M, K2, N, N, K2, code, b_mode=K.OP_K, out_t=dz, ldo_t=K2, aux=dev(gp, code), ld_aux=K2,
-           act=K.ACT_GELU_BWD, tile_hint=hint if hint != 7 else 3)
+           act=K.ACT_GELU_BWD, tile_hint=hint)
     check(dz, (dy @ w2) * gp, code, f'folded tail NN hint {hint} M {M}')
     # narrow / ragged N (non-coalesced epilogue path): N = 200
     w3 = q(rnd(200, K_, seed=8, scale=0.05), code)

@@ -19,6 +19,10 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 OPT = dict(type='SGD', momentum=0.9, weight_decay=0.0, paramwise_cfg=dict(custom_keys={'head': dict(lr_mult=10.)}))
 
 
+class _SampleView(dict):
+    """the recorded samples ARE the strided samples already: C.grad_sample of a 64-element vector returns it unchanged"""
+
+
 def load_gold(name):
     z = np.load(os.path.join(GOLD, f'step_{name}.npz'), allow_pickle=False)
     return z, json.loads(str(z['meta']))
@@ -46,7 +50,8 @@ def run_product(model, opt, sched, meta, iters=2):
         out['loss'].backward()
         torch.cuda.synchronize()        # (also joins the side stream: device-wide)
         gn = {n: float(p.grad.norm()) for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
-        rec.append(dict(log=out['log_vars'], gn=gn))
+        gs = {n: C.grad_sample(p.grad).clone() for n, p in model.named_parameters() if p.requires_grad and p.grad is not None}
+        rec.append(dict(log=out['log_vars'], gn=gn, g=gs))
         opt.step()
     torch.cuda.synchronize()
     return rec
@@ -60,6 +65,7 @@ def test_step_vs_golden(name, dtype):
     rec = run_product(model, opt, sched, meta)
     ltol = {'fp32': (1e-4, 1e-3), 'bf16': (2e-2, 4e-2)}[dtype]
     gtol = {'fp32': (1e-3, 5e-3), 'bf16': (8e-2, 1.5e-1)}[dtype]
+    etol = {'fp32': (1e-4, 2e-2), 'bf16': (5e-1, 5e-1)}[dtype]      # (worst tensor; the median over tensors is held to a tenth)
     msgs = []
     for it in range(2):
         keys = [str(k) for k in z[f'it{it}_loss_keys']]
@@ -83,6 +89,9 @@ def test_step_vs_golden(name, dtype):
                 worst = (e, k)
         if worst[0] > gtol[it]:
             msgs.append(f'it{it} grad norm {worst[1]}: rel {worst[0]:.2e}')
+        # ELEMENTS of every parameter's gradient (64 strided samples each, incl. in_proj, out_proj, fc1 / fc2, conv 3x3, BN
+        # gamma / beta, pos_embed): north_star's 1e-4 in fp32 at iteration 0, relative to the tensor's largest element
+        C.check_grad_samples(z, it, _SampleView(rec[it]['g']), etol[it], msgs)
     # state after two optimiser steps (student and EMA teacher)
     sd = model.state_dict()
     wtol = 2e-4 if dtype == 'fp32' else 2e-2
@@ -93,8 +102,16 @@ def test_step_vs_golden(name, dtype):
     assert not msgs, '\n'.join(msgs[:20])
 
 
-@pytest.mark.parametrize('dtype', ['fp32'])
+LOGIT_TOL = 2e-5     # stated bound on the fp32-mode teacher logits' deviation, relative to max |logit|
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_teacher_pseudo_labels_vs_golden(dtype):
+    """north_star: bit-exact argmax pseudo-label masks.  The labels come out of a full teacher forward (~40 kernels whose fp32
+    summation order differs from ATen's), so the logits agree to LOGIT_TOL, not to the bit; the masks must then be EQUAL on
+    every pixel whose decision the reference itself takes by more than that bound - top-2 logit margin and distance of
+    p_max to the threshold, both stored in the golden by the reference's own code (tests/common.fragile_pixels).  A mismatch
+    anywhere else fails.  bf16 perf mode (bf16 MFMA operands in the teacher forward): an agreement floor."""
     z, meta = load_gold('mt_pasa')
     model, opt, sched = build_product(meta, dtype)
     run_product(model, opt, sched, meta)
@@ -106,12 +123,21 @@ def test_teacher_pseudo_labels_vs_golden(dtype):
         model.set_train(True)
     lab = info['hard_seg_label'].cpu().numpy()
     ref = z['teacher_label_final']
-    mism = float((lab != ref).mean())
-    # bit-exact on identical logits is tested at kernel level; here the logits come out of ~40 fp32 kernels whose
-    # summation order differs from ATen's, so isolated near-tie / near-threshold pixels may flip
-    assert mism < 2e-3, f'{mism:.4%} pseudo-label pixels differ'
+    mism = lab != ref
     mr = float(info['conf_count']) / lab.size
-    assert abs(mr - float(z['teacher_mask_ratio_final'])) < 2e-3
+    if dtype == 'fp32':
+        tol = LOGIT_TOL * float(z['teacher_logit_absmax_final'])
+        fragile = C.fragile_pixels(z, tol)
+        bad = mism & ~fragile
+        print(f'fp32: {int(mism.sum())} of {lab.size} pixels differ, {int(fragile.sum())} are ties within {tol:.2e}, '
+              f'{int(bad.sum())} differ outside the tie set')
+        assert not bad.any(), f'{int(bad.sum())} pseudo-label pixels differ outside the tie set (logit bound {tol:.2e})'
+        assert float(fragile.mean()) < 0.01, 'the tie set must stay a small minority'
+        assert abs(mr - float(z['teacher_mask_ratio_final'])) < 2e-3
+    else:
+        print(f'bf16: {int(mism.sum())} of {lab.size} pixels differ')
+        assert float(mism.mean()) < 0.03, f'{float(mism.mean()):.2%} of the bf16 pseudo-labels differ from the reference'
+        assert abs(mr - float(z['teacher_mask_ratio_final'])) < 3e-2
 
 
 def test_plain_mt_pseudo_loss_vs_oracle():
@@ -214,4 +240,73 @@ def test_lockstep_heads_match_the_sequential_heads(name, monkeypatch):
             assert abs(float(a['log'][k]) - float(b['log'][k])) <= 1e-5 * abs(float(a['log'][k])) + 1e-7, (it, k)
         assert set(a['gn']) == set(b['gn'])
         for n in a['gn']:
-            assert abs(a['gn'][n] - b['gn'][n]) <= 1e-4 * a['gn'][n] + 1e-9, (it, n, a['gn'][n], b['gn'][n])
+            # (iteration 1 sits behind an optimiser step: atomics noise of iteration 0 can flip a ReLU decision that is within
+            # rounding of zero - one pixel's term, ~2e-4 of a norm)
+            assert abs(a['gn'][n] - b['gn'][n]) <= (1e-4, 1e-3)[it] * a['gn'][n] + 1e-9, (it, n, a['gn'][n], b['gn'][n])
+
+
+def test_unfused_two_pass_step_with_eager_sgd():
+    """A batch WITHOUT a 'sup' group takes the unfused foward_unsup_train path: with attn_mask_seperate_head every encoder layer
+    runs twice in one step (masked + plain student pass).  A layer's arena range must be reported final after the SECOND
+    backward only (ParamStore.range_acquire / range_release); reported after the first, the eager optimiser would step the
+    layer between the two passes.  Same final state as the plain optimiser step."""
+    z, meta = load_gold('mt_pasa')
+    finals = []
+    for eager in (False, True):
+        model, opt, sched = build_product(meta, 'fp32')
+        model.ensure_engine(torch.device('cuda', 0))
+        reported = []
+        if eager:
+            opt.attach_eager(model.student_store)
+            inner = model.student_store.on_range_done
+            model.student_store.on_range_done = lambda a, b: (reported.append((a, b)), inner(a, b))
+        for it in range(2):
+            imgs, gt, metas = C.make_batch(meta['seed_b'] + it, 0, 2)
+            sched.step(it)
+            opt.zero_grad()
+            out = model.train_step(dict(img=imgs.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda()), opt, iter=it)
+            assert 'loss_seg_unsup_attn_mask' in out['log_vars'] and 'loss_seg_unsup' in out['log_vars']
+            out['loss'].backward()
+            opt.step()
+        torch.cuda.synchronize()
+        if eager:
+            per_step = len(reported) // 2
+            assert sorted(reported[:per_step]) == sorted(set(reported)), 'a range was reported twice in one step'
+        finals.append((model.student_store.flat.clone(), model.student_store.mom.clone()))
+    for p, e in zip(*finals):
+        assert float((e - p).abs().max()) <= 1e-3 * float(p.abs().max())
+
+
+def test_optimizer_state_dict_round_trip():
+    """optimizer.state_dict() carries the SGD momentum (torch layout: state[i]['momentum_buffer']), as the reference's mmcv
+    checkpoints do; a model + optimiser restored from the two state dicts continues exactly like the original."""
+    z, meta = load_gold('sup')
+    model, opt, sched = build_product(meta, 'fp32')
+    run_product(model, opt, sched, meta, iters=2)
+    osd, msd = opt.state_dict(), {k: v.clone() for k, v in model.state_dict().items()}
+    named = dict(model.named_parameters())
+    n_train = sum(1 for p in named.values() if p.requires_grad)
+    assert len(osd['state']) == n_train and all('momentum_buffer' in s for s in osd['state'].values())
+    i0 = next(i for i, g in enumerate(opt.param_groups) if g['name'] == 'backbone.layers.0.ffn.layers.1.weight')
+    assert tuple(osd['state'][i0]['momentum_buffer'].shape) == tuple(named['backbone.layers.0.ffn.layers.1.weight'].shape)
+    assert float(osd['state'][i0]['momentum_buffer'].abs().sum()) > 0
+
+    model2, opt2, sched2 = build_product(meta, 'fp32')
+    model2.load_state_dict(msd, strict=True)
+    model2.ensure_engine(torch.device('cuda', 0))
+    opt2.load_state_dict(osd)
+    assert not model2.student_store.first_sgd_step
+    assert torch.equal(model2.student_store.mom, model.student_store.mom)
+    # save -> load -> save keeps num_batches_tracked (host counters are reset by the load)
+    nbt = {k: int(v) for k, v in msd.items() if k.endswith('num_batches_tracked')}
+    assert {k: int(v) for k, v in model2.state_dict().items() if k.endswith('num_batches_tracked')} == nbt
+    assert any(v > 0 for v in nbt.values())
+    for m_, o_, s_ in ((model, opt, sched), (model2, opt2, sched2)):
+        imgs, gt, metas = C.make_batch(meta['seed_b'] + 2, meta['n_sup'], meta['n_unsup'])
+        s_.step(2)
+        o_.zero_grad()
+        m_.train_step(dict(img=imgs.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda()), o_, iter=2)['loss'].backward()
+        o_.step()
+    torch.cuda.synchronize()
+    d = float((model.student_store.flat - model2.student_store.flat).abs().max())
+    assert d <= 1e-5 * float(model.student_store.flat.abs().max()), d
