@@ -205,6 +205,27 @@ int s4f_up_pseudo_label(const float* logits_lo, uint8_t* label_out, uint8_t* con
 /* full-resolution logits for the mmseg API: out fp32 NCHW [B, C, h*s, w*s] = up_s(logits_lo) */
 int s4f_up_logits_nchw(const float* logits_lo, float* out, int B, int h, int w, int C, int ldc, int s, s4f_stream stream);
 
+/* ---- S4Former "ours" additions (configs/setr/..._MT_w_ours.py) -------------------------------------------------------
+ * Negative class ranking, mode 'unsup_only' (mmseg/models/segmentors/encoder_decoder.py:936-954): for every pixel with
+ * label c < C (255 = not confident: no term) softmax over the classes != c of the up-sampled student / teacher logits,
+ * d = || p_s - p_t + 1e-6 ||_2 (nn.PairwiseDistance); loss_sum += sum of d.  Both logit maps are fp32 low-resolution
+ * [B*h*w, ldc], up-sampled x s on the fly (bilinear, align_corners=False). */
+int s4f_ncr_fwd(const float* student_lo, const float* teacher_lo, const uint8_t* labels, float* loss_sum, int B, int h, int w,
+                int C, int ldc, int s, s4f_stream stream);
+/* dlo += gscale * (*gscale_dev) * d loss_sum / d student_lo  (dlo already holds the CE gradient of the same logits);
+ * dlo_t (dtype) receives the rounded sum when not NULL. */
+int s4f_ncr_bwd(const float* student_lo, const float* teacher_lo, const uint8_t* labels, float gscale, const float* gscale_dev,
+                float* dlo, void* dlo_t, int B, int h, int w, int C, int ldc, int s, int dtype, s4f_stream stream);
+/* CutMix + PatchShuffle of the unlabeled student images in one gather (mmseg/utils/generate_unsup_data.py:400-453, 737-819):
+ * cut-mixed image b = img[b] outside box[b] = (y0, y1, x0, x1), img[(b+1) % B] inside; PatchShuffle puts block perm[b][p]
+ * of it at block position p (block x block pixels, row-major block index, square images).  fp32 NCHW. */
+int s4f_mix_images(const float* img, float* out, const int* box, const int* perm, int B, int C, int H, int W, int block,
+                   s4f_stream stream);
+/* the same CutMix on the uint8 pseudo-labels [B, H, W] (labels are not shuffled) */
+int s4f_cutmix_labels(const uint8_t* labels, uint8_t* out, const int* box, int B, int H, int W, s4f_stream stream);
+/* out[r, :] = src[map[r], :]  (fp32 rows of C floats): the token un-shuffle of decode_head.py:186-212 and its adjoint */
+int s4f_gather_rows(const float* src, float* out, const int* map, int64_t rows, int C, s4f_stream stream);
+
 /* Stand-alone CrossEntropyLoss on NCHW / [N,C] fp32 logits (cross_entropy_loss.py:12-63): per-element loss
  * (0 where ignored), optional class weights; spatial = H*W (1 for [N,C]). */
 int s4f_ce_fwd(const float* logits, const int64_t* labels, const float* class_weight, float* loss_elem, int64_t N,

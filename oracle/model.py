@@ -109,10 +109,12 @@ class OracleHead(nn.Module):
             self.up_convs.append(nn.Sequential(OracleConvModule(cin, channels), OracleUpsample(up_scale)))
             cin = channels
 
-    def forward(self, inputs):
+    def forward(self, inputs, patchmix_n=0, perms=None):
         x = inputs[self.in_index]
         n, c, h, w = x.shape
         x = x.reshape(n, c, h * w).transpose(2, 1).contiguous()
+        if patchmix_n:
+            x = O.repatchmix_tokens(x, perms, patchmix_n)        # setr_up_head.py:98-100
         x = self.norm(x)
         x = x.transpose(1, 2).reshape(n, c, h, w).contiguous()
         for up in self.up_convs:
@@ -132,7 +134,9 @@ class OracleSegmentor(nn.Module):
 
     def __init__(self, backbone, decode_head, auxiliary_head=None, ema=True, ema_momentum=0.999, unsup_weight=1.0,
                  unsup_confidence=0.95, attn_mask_seperate_head=False, attn_mask_weight=50, adaptive_attn_mask=False,
-                 fdrop_loss_weight=0.5, patchsize=16, plain_mt_pseudo_loss=False):
+                 fdrop_loss_weight=0.5, patchsize=16, plain_mt_pseudo_loss=False, use_PatchShuffle_w_Cutmix=False, PatchMix_N=8,
+                 patchmix_ratio=0.5, strong_aug_prob=0.5, cutout_area=2, negative_class_ranking=False,
+                 negative_class_ranking_mode='sup_only'):
         super().__init__()
         self.backbone = OracleViT(**backbone)
         self.decode_head = OracleHead(**decode_head)
@@ -142,6 +146,10 @@ class OracleSegmentor(nn.Module):
         self.attn_mask_seperate_head, self.attn_mask_weight = attn_mask_seperate_head, attn_mask_weight
         self.adaptive_attn_mask, self.fdrop_loss_weight, self.patchsize = adaptive_attn_mask, fdrop_loss_weight, patchsize
         self.plain_mt_pseudo_loss = plain_mt_pseudo_loss
+        self.use_PatchShuffle_w_Cutmix, self.PatchMix_N, self.patchmix_ratio = use_PatchShuffle_w_Cutmix, PatchMix_N, patchmix_ratio
+        self.strong_aug_prob, self.cutout_area = strong_aug_prob, cutout_area
+        self.negative_class_ranking = negative_class_ranking and negative_class_ranking_mode in ('unsup_only', 'both')
+        assert not negative_class_ranking or negative_class_ranking_mode == 'unsup_only', 'oracle restates mode unsup_only'
         if ema:
             self.backbone_ema = OracleViT(**backbone)
             self.decode_head_ema = OracleHead(**decode_head)
@@ -174,12 +182,15 @@ class OracleSegmentor(nn.Module):
             self.backbone_ema.train(); self.decode_head_ema.train()
         return dict(seg_logits=seg_logits, hard_seg_label=label, conf_mask=conf)
 
-    def compute_pseudo_loss(self, feat, tinfo):
-        """encoder_decoder.py:906-934"""
-        pred = self.decode_head(feat)
+    def compute_pseudo_loss(self, feat, tinfo, patchmix_n=0, perms=None):
+        """encoder_decoder.py:906-954 (NCR: mode 'unsup_only')"""
+        pred = self.decode_head(feat, patchmix_n, perms)
         loss = O.ce_none(pred, tinfo['hard_seg_label'], 255)
         mask_ratio = torch.sum(tinfo['conf_mask']).float() / torch.sum(torch.ones_like(loss))
-        return dict(loss_seg_unsup=torch.mean(loss * torch.ones_like(loss)), mask_ratio=mask_ratio)
+        out = dict(loss_seg_unsup=torch.mean(loss * torch.ones_like(loss)), mask_ratio=mask_ratio)
+        if self.negative_class_ranking:
+            out['loss_ncr_unsup'] = O.ncr_unsup_only(pred, tinfo['seg_logits'], tinfo['hard_seg_label'])
+        return out
 
     def forward_train(self, img, tags, gt_semantic_seg):
         losses = OrderedDict()
@@ -206,12 +217,27 @@ class OracleSegmentor(nn.Module):
                 feat = self.backbone(simg, attn_mask=u, attn_mask_weight=self.attn_mask_weight,
                                      adaptive_attn_mask=self.adaptive_attn_mask)
                 unsup['loss_seg_unsup_attn_mask'] = self.compute_pseudo_loss(feat, tinfo)['loss_seg_unsup'] * 0.5
+                pm_n, perms = 0, None
+                if self.use_PatchShuffle_w_Cutmix:
+                    # encoder_decoder.py:633-638: CutMix (images + pseudo-labels; conf_mask and seg_logits stay), then
+                    # PatchShuffle of the images; the decode head un-shuffles the tokens (labels stay in place)
+                    tinfo = dict(tinfo)
+                    boxes, perms = O.draw_strong_aug(simg.shape[0], tuple(simg.shape[2:]), self.strong_aug_prob, self.cutout_area,
+                                                     self.patchmix_ratio, self.patchsize * self.PatchMix_N)
+                    simg, tinfo['hard_seg_label'] = O.cutmix(simg, tinfo['hard_seg_label'], boxes)
+                    simg = O.patch_shuffle(simg, perms, self.patchsize * self.PatchMix_N)
+                    pm_n = self.PatchMix_N
                 feat = self.backbone(simg)
+                r = self.compute_pseudo_loss(feat, tinfo, pm_n, perms)
+                self.last['mask_ratio'] = r['mask_ratio']
+                if self.negative_class_ranking:
+                    unsup['loss_ncr_unsup'] = r['loss_ncr_unsup'] * 0.5
+                unsup['loss_seg_unsup'] = r['loss_seg_unsup'] * self.fdrop_loss_weight
             else:
                 u = self._patch_u(tinfo['conf_mask'])
                 feat = self.backbone(simg, attn_mask=u, attn_mask_weight=self.attn_mask_weight,
                                      adaptive_attn_mask=self.adaptive_attn_mask)
-            if self.attn_mask_seperate_head or self.plain_mt_pseudo_loss:
+            if self.plain_mt_pseudo_loss and not self.attn_mask_seperate_head:
                 r = self.compute_pseudo_loss(feat, tinfo)
                 self.last['mask_ratio'] = r['mask_ratio']
                 unsup['loss_seg_unsup'] = r['loss_seg_unsup'] * self.fdrop_loss_weight
@@ -271,4 +297,8 @@ def oracle_from_cfg(model_cfg):
         attn_mask_seperate_head=model_cfg.get('attn_mask_seperate_head', False),
         attn_mask_weight=model_cfg.get('attn_mask_weight', 50), adaptive_attn_mask=model_cfg.get('adaptive_attn_mask', False),
         fdrop_loss_weight=model_cfg.get('fdrop_loss_weight', 0.5), patchsize=model_cfg.get('patchsize', 16),
-        plain_mt_pseudo_loss=model_cfg.get('plain_mt_pseudo_loss', False))
+        plain_mt_pseudo_loss=model_cfg.get('plain_mt_pseudo_loss', False),
+        use_PatchShuffle_w_Cutmix=model_cfg.get('use_PatchShuffle_w_Cutmix', False), PatchMix_N=model_cfg.get('PatchMix_N', 8),
+        patchmix_ratio=model_cfg.get('patchmix_ratio', 0.5), strong_aug_prob=model_cfg.get('strong_aug_prob', 0.5),
+        cutout_area=model_cfg.get('cutout_area', 2), negative_class_ranking=model_cfg.get('negative_class_ranking', False),
+        negative_class_ranking_mode=model_cfg.get('negative_class_ranking_mode', 'sup_only'))

@@ -142,3 +142,97 @@ def poly_lr(base_lr, it, max_iters, power=0.9, min_lr=1e-4):
     """mmcv PolyLrUpdaterHook (schedule_80k_pascal_1over8.py:5): by_epoch=False."""
     coeff = (1 - it / max_iters) ** power
     return (base_lr - min_lr) * coeff + min_lr
+
+
+# ---------------------------------------------------------------------------------------------- "ours" additions (§8f-1)
+def cutout_box(img_size, ratio=2):
+    """generate_cutout_mask (mmseg/utils/generate_unsup_data.py:7-26) as the box (y0, y1, x0, x1) it zeroes, drawing from
+    numpy's GLOBAL generator in the reference's call order (randint w, randint x_start, randint y_start)."""
+    import numpy as np
+    H, W = img_size
+    area = H * W / ratio
+    w = np.random.randint(W / ratio + 1, W)
+    h = np.round(area / w)
+    x0 = np.random.randint(0, W - w + 1)
+    y0 = np.random.randint(0, H - h + 1)
+    return int(y0), int(y0 + h), int(x0), int(x0 + w)
+
+
+def cutmix(img, label, boxes):
+    """generate_unsup_cutmix_data (generate_unsup_data.py:400-453, patchwise=False): image / label i keeps itself where
+    mask == 1 and takes sample (i + 1) % B inside box i.  (The reference routes the labels through a float + nearest
+    resize round trip of identical size: the identity.)"""
+    B = img.shape[0]
+    new_img, new_lab = img.clone(), label.clone()
+    for i, (y0, y1, x0, x1) in enumerate(boxes):
+        j = (i + 1) % B
+        new_img[i, :, y0:y1, x0:x1] = img[j, :, y0:y1, x0:x1]
+        new_lab[i, y0:y1, x0:x1] = label[j, y0:y1, x0:x1]
+    return new_img, new_lab
+
+
+def patch_shuffle(img, perms, block):
+    """generate_unsup_patchmix_data (generate_unsup_data.py:737-819): block position p of image b receives block perms[b][p]
+    (row-major block index over the (H / block) x (W / block) grid)."""
+    B, C, H, W = img.shape
+    G = W // block
+    out = img.clone()
+    for b in range(B):
+        for p in range(G * G):
+            s = int(perms[b][p])
+            out[b, :, (p // G) * block:(p // G + 1) * block, (p % G) * block:(p % G + 1) * block] = \
+                img[b, :, (s // G) * block:(s // G + 1) * block, (s % G) * block:(s % G + 1) * block]
+    return out
+
+
+def draw_strong_aug(B, img_size, strong_aug_prob=0.5, cutout_ratio=2, patchmix_ratio=0.5, block=128):
+    """the random decisions of the use_PatchShuffle_w_Cutmix branch (encoder_decoder.py:633-638) in the reference's order of
+    RNG calls: np.random.uniform (CutMix at all?), per image the cut-out box, then per image np.random.rand (shuffle?) and
+    torch.randperm over the blocks.  Returns (boxes [(y0, y1, x0, x1)] - empty boxes when CutMix is skipped, perms)."""
+    import numpy as np
+    H, W = img_size
+    if np.random.uniform(0, 1) < strong_aug_prob:
+        boxes = [cutout_box(img_size, cutout_ratio) for _ in range(B)]
+    else:
+        boxes = [(0, 0, 0, 0)] * B
+    n = (H // block) * (W // block)
+    perms = []
+    for _ in range(B):
+        if np.random.rand() < patchmix_ratio:
+            perms.append(torch.arange(n)[torch.randperm(n)])
+        else:
+            perms.append(torch.arange(n))
+    return boxes, perms
+
+
+def repatchmix_tokens(tokens, perms, n):
+    """BaseDecodeHead._repatchmix_inputs (decode_heads/decode_head.py:186-212): tokens [B, T, C] of a patch-shuffled image
+    (T = g x g patches, shuffled in blocks of n x n patches) back in the original block order: block q of the result is the
+    block at the position p with perms[b][p] == q."""
+    B, T, C = tokens.shape
+    g = int(round(T ** 0.5))
+    G = g // n
+    x = tokens.reshape(B, G, n, G, n, C)
+    out = torch.empty_like(x)
+    for b in range(B):
+        for p in range(G * G):
+            q = int(perms[b][p])
+            out[b, q // G, :, q % G] = x[b, p // G, :, p % G]
+    return out.reshape(B, T, C)
+
+
+def ncr_unsup_only(student_logits, teacher_logits, hard_label):
+    """compute_pseudo_loss, negative_class_ranking_mode == 'unsup_only' (encoder_decoder.py:936-954): per class c the pixels
+    labelled c, student / teacher logits without channel c, softmax over the rest, nn.PairwiseDistance(p=2) (eps 1e-6 added
+    to the difference), summed, divided by B H W."""
+    B, C, H, W = teacher_logits.shape
+    s = student_logits.permute(0, 2, 3, 1)
+    t = teacher_logits.permute(0, 2, 3, 1)
+    pdist = torch.nn.PairwiseDistance(p=2)
+    loss = 0
+    for c in range(C):
+        m = hard_label == c
+        sc = torch.cat((s[m][:, :c], s[m][:, c + 1:]), dim=1)
+        tc = torch.cat((t[m][:, :c], t[m][:, c + 1:]), dim=1)
+        loss = loss + torch.sum(pdist(F.softmax(sc, dim=1), F.softmax(tc, dim=1)))
+    return loss / (B * H * W)

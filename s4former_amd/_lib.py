@@ -72,6 +72,12 @@ _SIGS = {
     's4f_up_pseudo_label': [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_int,
                             c_int, c_void_p],
     's4f_up_logits_nchw': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_ncr_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_ncr_bwd': [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                    c_void_p],
+    's4f_mix_images': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_cutmix_labels': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    's4f_gather_rows': [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     's4f_ce_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p],
     's4f_ce_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p],
     's4f_ema': [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p],

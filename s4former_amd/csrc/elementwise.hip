@@ -371,6 +371,72 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
   }
 }
 
+// ------------------------------------------------------------------------------------------ in-model strong augmentations
+// CutMix + PatchShuffle of the unlabeled student images in ONE gather (reference mmseg/utils/generate_unsup_data.py:400-453,
+// 737-819): the cut-mixed image b is img[b] outside its box and img[(b + 1) % B] inside (mask == 0 inside
+// [y0, y1) x [x0, x1)); PatchShuffle then places block perm[b][p] of that image at block position p (blocks of
+// `block` x `block` pixels, row-major block index).  box: int32 [B][4] = y0, y1, x0, x1 (empty box = no CutMix);
+// perm: int32 [B][G*G] (identity = no shuffle).
+__global__ __launch_bounds__(256) void mix_images_kernel(const float* __restrict__ img, float* __restrict__ out,
+                                                         const int* __restrict__ box, const int* __restrict__ perm, int B, int C,
+                                                         int H, int W, int block) {
+  const int G = W / block;
+  const long total = (long)B * C * H * (W / 4);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int x4 = i % (W / 4);
+    long t = i / (W / 4);
+    const int y = t % H; t /= H;
+    const int c = t % C;
+    const int b = t / C;
+    const int x = x4 * 4;
+    const int pos = (y / block) * G + x / block;
+    const int src = perm[b * G * G + pos];
+    const int sy = (src / G) * block + y % block, sx = (src % G) * block + x % block;
+    const int* bx = box + 4 * b;
+    const float* p0 = img + (((long)b * C + c) * H + sy) * W + sx;
+    const float* p1 = img + (((long)((b + 1) % B) * C + c) * H + sy) * W + sx;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p0);
+    if (sy >= bx[0] && sy < bx[1]) {
+      const f32x4 o = *reinterpret_cast<const f32x4*>(p1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (sx + e >= bx[2] && sx + e < bx[3]) v[e] = o[e];
+    }
+    *reinterpret_cast<f32x4*>(out + (((long)b * C + c) * H + y) * W + x) = v;
+  }
+}
+
+// CutMix of the pseudo-labels (the labels are NOT shuffled: the head un-shuffles the features instead)
+__global__ __launch_bounds__(256) void cutmix_labels_kernel(const uint8_t* __restrict__ lab, uint8_t* __restrict__ out,
+                                                            const int* __restrict__ box, int B, int H, int W) {
+  const long total = (long)B * H * W;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int x = i % W;
+    const long t = i / W;
+    const int y = t % H;
+    const int b = t / H;
+    const int* bx = box + 4 * b;
+    const bool in = y >= bx[0] && y < bx[1] && x >= bx[2] && x < bx[3];
+    out[i] = in ? lab[((long)((b + 1) % B) * H + y) * W + x] : lab[i];
+  }
+}
+
+// out row r = src row map[r] (rows of C floats; C % 4 == 0): the token un-shuffle of decode_head.py:186-212 and its adjoint
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, float* __restrict__ out,
+                                                          const int* __restrict__ map, long rows, int C) {
+  const int c4 = C / 4;
+  const long total = rows * c4;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const long r = i / c4;
+    const int c = (int)(i - r * c4) * 4;
+    *reinterpret_cast<f32x4*>(out + r * C + c) = *reinterpret_cast<const f32x4*>(src + (long)map[r] * C + c);
+  }
+}
+
+
 }  // namespace
 
 
@@ -527,6 +593,30 @@ S4F_API int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean,
   if (grid > 512) grid = 512;
   if (dtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)dy, x, mean, rstd, gamma, dresid, dx, (bf16_t*)dx_t, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
   else { LN_DISPATCH(ln_bwd_kernel, float, (const float*)dy, x, mean, rstd, gamma, dresid, dx, (float*)dx_t, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_mix_images(const float* img, float* out, const int* box, const int* perm, int B, int C, int H, int W, int block,
+                           s4f_stream stream) {
+  S4F_CHECK(img && out && box && perm && img != out, "s4f_mix_images: null / aliased pointer");
+  S4F_CHECK(B > 0 && C > 0 && block > 0 && block % 4 == 0 && H % block == 0 && W % block == 0 && H == W,
+            "s4f_mix_images: square images of whole blocks expected (H=%d W=%d block=%d)", H, W, block);
+  hipLaunchKernelGGL(mix_images_kernel, dim3(grid_for((long)B * C * H * (W / 4), 256)), dim3(256), 0, (hipStream_t)stream, img, out, box, perm, B, C, H, W, block);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_cutmix_labels(const uint8_t* labels, uint8_t* out, const int* box, int B, int H, int W, s4f_stream stream) {
+  S4F_CHECK(labels && out && box && labels != out && B > 0 && H > 0 && W > 0, "s4f_cutmix_labels: bad args");
+  hipLaunchKernelGGL(cutmix_labels_kernel, dim3(grid_for((long)B * H * W, 256)), dim3(256), 0, (hipStream_t)stream, labels, out, box, B, H, W);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_gather_rows(const float* src, float* out, const int* map, int64_t rows, int C, s4f_stream stream) {
+  S4F_CHECK(src && out && map && src != out && rows > 0 && C > 0 && C % 4 == 0, "s4f_gather_rows: bad args");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, src, out, map, (long)rows, C);
   S4F_LAUNCH_CHECK();
   return 0;
 }

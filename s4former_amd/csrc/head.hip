@@ -1040,6 +1040,117 @@ __global__ __launch_bounds__(256) void up_logits_nchw_kernel(const float* __rest
   }
 }
 
+
+// ------------------------------------------------------------------------------------------ negative class ranking (NCR)
+// reference encoder_decoder.py:936-954 (mode 'unsup_only'): for every pixel with a pseudo-label c != 255 the student and the
+// teacher logits WITHOUT class c are soft-maxed over the remaining C - 1 classes and compared by
+// nn.PairwiseDistance(p = 2): d = || p_s - p_t + 1e-6 ||_2; loss = sum d / (B H W).  Both logit maps are the bilinear
+// up-sampling (x s) of low-resolution logits, sampled on the fly.  Only the student side carries a gradient.
+__device__ __forceinline__ float ncr_pixel(const float (&zs)[kMaxC], const float (&zt)[kMaxC], int lab, int C, float (&ps)[kMaxC],
+                                           float (&v)[kMaxC]) {
+  float ms = -INFINITY, mt = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < kMaxC; ++c)
+    if (c < C && c != lab) { ms = fmaxf(ms, zs[c]); mt = fmaxf(mt, zt[c]); }
+  float ss = 0.f, st = 0.f;
+  float pt[kMaxC];
+#pragma unroll
+  for (int c = 0; c < kMaxC; ++c) {
+    const bool on = c < C && c != lab;
+    ps[c] = on ? expf(zs[c] - ms) : 0.f;
+    pt[c] = on ? expf(zt[c] - mt) : 0.f;
+    ss += ps[c];
+    st += pt[c];
+  }
+  const float is = 1.f / ss, it = 1.f / st;
+  float d2 = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxC; ++c) {
+    const bool on = c < C && c != lab;
+    ps[c] *= is;
+    v[c] = on ? (ps[c] - pt[c] * it + 1e-6f) : 0.f;
+    d2 += v[c] * v[c];
+  }
+  return sqrtf(d2);
+}
+
+__global__ __launch_bounds__(256) void ncr_fwd_kernel(const float* __restrict__ slo, const float* __restrict__ tlo,
+                                                      const uint8_t* __restrict__ labels, float* __restrict__ loss_sum, int B, int h,
+                                                      int w, int C, int ldc, int s) {
+  __shared__ float red[4];
+  const int H = h * s, W = w * s;
+  const long total = (long)B * H * W;
+  const long stride = (long)gridDim.x * blockDim.x;
+  float lsum = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int lab = labels[i];
+    if (lab >= C) continue;                                  // 255 (not confident): no class matches, no term
+    const int ox = i % W;
+    const long t = i / W;
+    const int oy = t % H;
+    const int b = t / H;
+    float zs[kMaxC], zt[kMaxC], ps[kMaxC], v[kMaxC];
+    sample_logits(slo, b, oy, ox, h, w, C, ldc, s, zs);
+    sample_logits(tlo, b, oy, ox, h, w, C, ldc, s, zt);
+    lsum += ncr_pixel(zs, zt, lab, C, ps, v);
+  }
+  const float tot = block_sum_256(lsum, red);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, tot);
+}
+
+// gradient w.r.t. the student's LOW-resolution logits, ACCUMULATED into dlo (which already holds the CE gradient of the same
+// logits): one thread per low-res pixel gathers over the high-res pixels that read it (transposed bilinear stencil).
+// d d / d z_k = p_k (u_k - sum_j p_j u_j), u = (p_s - p_t + eps) / d  over the classes k != c.
+template <typename T>
+__global__ __launch_bounds__(256) void ncr_bwd_kernel(const float* __restrict__ slo, const float* __restrict__ tlo,
+                                                      const uint8_t* __restrict__ labels, float gscale,
+                                                      const float* __restrict__ gscale_dev, float* __restrict__ dlo,
+                                                      T* __restrict__ dlo_t, int B, int h, int w, int C, int ldc, int s) {
+  const int H = h * s, W = w * s;
+  const long total = (long)B * h * w;
+  if (gscale_dev) gscale *= *gscale_dev;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long p = (long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += stride) {
+    const int j = p % w;
+    const long t = p / w;
+    const int i = t % h;
+    const int b = t / h;
+    float acc[kMaxC];
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c) acc[c] = 0.f;
+    const int oy0 = s == 1 ? i : max(0, s * i - s), oy1 = s == 1 ? i : min(H - 1, s * i + 2 * s - 1);
+    const int ox0 = s == 1 ? j : max(0, s * j - s), ox1 = s == 1 ? j : min(W - 1, s * j + 2 * s - 1);
+    for (int oy = oy0; oy <= oy1; ++oy) {
+      const float wy = lerp_w(oy, i, s, h);
+      if (wy == 0.f) continue;
+      for (int ox = ox0; ox <= ox1; ++ox) {
+        const float wgt = wy * lerp_w(ox, j, s, w);
+        if (wgt == 0.f) continue;
+        const int lab = labels[((long)b * H + oy) * W + ox];
+        if (lab >= C) continue;
+        float zs[kMaxC], zt[kMaxC], ps[kMaxC], v[kMaxC];
+        sample_logits(slo, b, oy, ox, h, w, C, ldc, s, zs);
+        sample_logits(tlo, b, oy, ox, h, w, C, ldc, s, zt);
+        const float d = ncr_pixel(zs, zt, lab, C, ps, v);
+        if (d == 0.f) continue;                                // torch: the norm's gradient at 0 is 0
+        const float k = wgt * gscale / d;
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) dot += ps[c] * v[c];
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) acc[c] += k * ps[c] * (v[c] - dot);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < kMaxC; ++c)
+      if (c < ldc) {
+        const float g = dlo[p * ldc + c] + acc[c];
+        dlo[p * ldc + c] = g;
+        if (dlo_t) dlo_t[p * ldc + c] = from_f32<T>(g);
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------------ stand-alone CE (NCHW / [N,C])
 __global__ void ce_fwd_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                               const float* __restrict__ cw, float* __restrict__ loss, long N, int C, long spatial,
@@ -1301,6 +1412,30 @@ S4F_API int s4f_up_logits_nchw(const float* logits_lo, float* out, int B, int h,
   LOGIT_CHECK("s4f_up_logits_nchw");
   const long total = (long)B * h * s * w * s;
   hipLaunchKernelGGL(up_logits_nchw_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, logits_lo, out, B, h, w, C, ldc, s);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_ncr_fwd(const float* student_lo, const float* teacher_lo, const uint8_t* labels, float* loss_sum, int B, int h,
+                        int w, int C, int ldc, int s, s4f_stream stream) {
+  S4F_CHECK(student_lo && teacher_lo && labels && loss_sum, "s4f_ncr_fwd: null pointer");
+  LOGIT_CHECK("s4f_ncr_fwd");
+  S4F_CHECK(C >= 2, "s4f_ncr_fwd: needs at least two classes");
+  const long total = (long)B * h * s * w * s;
+  hipLaunchKernelGGL(ncr_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, student_lo, teacher_lo, labels, loss_sum, B, h, w, C, ldc, s);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_ncr_bwd(const float* student_lo, const float* teacher_lo, const uint8_t* labels, float gscale,
+                        const float* gscale_dev, float* dlo, void* dlo_t, int B, int h, int w, int C, int ldc, int s, int dtype,
+                        s4f_stream stream) {
+  S4F_CHECK(student_lo && teacher_lo && labels && dlo, "s4f_ncr_bwd: null pointer");
+  LOGIT_CHECK("s4f_ncr_bwd");
+  S4F_CHECK(dtype == S4F_F32 || dtype == S4F_BF16, "s4f_ncr_bwd: bad dtype %d", dtype);
+  const long total = (long)B * h * w;
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(ncr_bwd_kernel<bf16_t>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, student_lo, teacher_lo, labels, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, s);
+  else hipLaunchKernelGGL(ncr_bwd_kernel<float>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, student_lo, teacher_lo, labels, gscale, gscale_dev, dlo, (float*)nullptr, B, h, w, C, ldc, s);
   S4F_LAUNCH_CHECK();
   return 0;
 }

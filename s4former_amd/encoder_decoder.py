@@ -5,8 +5,10 @@ driving the MI355X HIP kernels: student + teacher replicas live in flat arenas (
 update is one launch, the teacher's pseudo-labels come from one fused kernel.
 
 Scope: the supervised branch, the mean-teacher EMA, teacher pseudo-labels with confidence threshold,
-the pseudo-label CE (`compute_pseudo_loss`), and the PASA attention bias (rank-1, never materialised).
-CutMix / PatchShuffle / NCR / UniMatch / fdrop switches are "next" rows and raise.
+the pseudo-label CE (`compute_pseudo_loss`), the PASA attention bias (rank-1, never materialised) and the "ours" additions
+of configs/setr/..._MT_w_ours.py: CutMix + PatchShuffle of the student images between the masked and the plain student pass
+(use_PatchShuffle_w_Cutmix), the decode head's token un-shuffle, and the negative-class-ranking loss (mode 'unsup_only').
+The other in-model augmentations / UniMatch / fdrop switches are outside SURVEY §8 and raise.
 """
 import os
 from collections import OrderedDict
@@ -131,8 +133,8 @@ _UNSUP_STREAM = os.environ.get('S4F_UNSUP_STREAM', 'decode')    # experiment: 'd
 
 _UNSUPPORTED_TRUE = ('sup_ema', 'attn_frozen', 'sup_ClassMix', 'sup_cutmix', 'unsup_soft', 'use_CutMix', 'use_CutOut',
                      'use_ClassMix', 'mix_with_labeled', 'patchwise', 'use_PatchShuffle', 'use_PatchShuffle_w_Classmix',
-                     'use_PatchShuffle_w_Cutmix', 'no_pos_embed', 'avg_pos_emd', 'duplicate_pos_emd', 'attn_mask_w_fdrop',
-                     'negative_class_ranking', 'use_fdrop', 'unimatch', 'use_cutmix_adaptive', 'ema_test')
+                     'no_pos_embed', 'avg_pos_emd', 'duplicate_pos_emd', 'attn_mask_w_fdrop',
+                     'use_fdrop', 'unimatch', 'use_cutmix_adaptive', 'ema_test')
 
 
 @SEGMENTORS.register_module()
@@ -176,6 +178,18 @@ class EncoderDecoder(BaseSegmentor):
         # extension (documented in DESIGN.md): the literal MT config never produces an unsupervised loss (Q1);
         # True runs compute_pseudo_loss on the plain mean-teacher branch as encoder_decoder.py:681-685 would.
         self.plain_mt_pseudo_loss = plain_mt_pseudo_loss
+        # "ours" (configs/setr/..._MT_w_ours.py:236-256)
+        if negative_class_ranking and negative_class_ranking_mode != 'unsup_only':
+            raise S4FError(f"negative_class_ranking_mode={negative_class_ranking_mode!r}: only 'unsup_only' (the mode of the SETR "
+                           'config) is built; the sup_only / both / kl variants are outside SURVEY §8')
+        if (negative_class_ranking or use_PatchShuffle_w_Cutmix) and not attn_mask_seperate_head:
+            raise S4FError('use_PatchShuffle_w_Cutmix / negative_class_ranking act on the plain student pass that '
+                           'attn_mask_seperate_head=True adds (encoder_decoder.py:633-687)')
+        if use_PatchShuffle_w_Cutmix and not isinstance(cutout_area, int):
+            raise S4FError('cutout_area must be an int')
+        self.use_PatchShuffle_w_Cutmix, self.patchmix_ratio = use_PatchShuffle_w_Cutmix, patchmix_ratio
+        self.strong_aug_prob, self.cutout_area = strong_aug_prob, cutout_area
+        self.negative_class_ranking = negative_class_ranking
         self.with_auxiliary_head_ema = False
         if self.ema:
             if self.momentum_backbone != self.momentum_head:
@@ -411,7 +425,10 @@ class EncoderDecoder(BaseSegmentor):
         ns, nu = sup_imgs.shape[0], simg.shape[0]
         u = self._conf_to_patch_u(teacher_info['conf_mask'])
         bu, flag, w = self.backbone._rank1_mask(u, self.attn_mask_weight, self.adaptive_attn_mask)
-        groups = [sup_imgs, simg] + ([simg] if self.attn_mask_seperate_head else [])
+        plain_img, aug = simg, None
+        if self.attn_mask_seperate_head and self.use_PatchShuffle_w_Cutmix:
+            plain_img, aug = self._strong_augment(simg, teacher_info)       # images of the plain pass, labels, token maps
+        groups = [sup_imgs, simg] + ([plain_img] if self.attn_mask_seperate_head else [])
         nb = sum(g.shape[0] for g in groups)
         # the batch usually is [sup..., unsup_student..., unsup_teacher...]: sup + student is then one contiguous view
         if not self.attn_mask_seperate_head and sup_imgs.data_ptr() + sup_imgs.numel() * 4 == simg.data_ptr() and \
@@ -431,7 +448,7 @@ class EncoderDecoder(BaseSegmentor):
         outs = self.backbone.forward_rank1(imgs, (bias_u, row_flag, w))
         f_sup = self.backbone.split_taps(outs, 0, ns)
         f_mask = self.backbone.split_taps(outs, ns, ns + nu)
-        if self._decode_lockstep():
+        if self._decode_lockstep() and aug is None and not self.negative_class_ranking:
             # N > 1: the decode head's calls (labelled, masked pseudo-labelled, plain pseudo-labelled) advance layer by layer
             # TOGETHER: one SyncBN exchange per layer for all of them; BN running statistics are updated in call order
             dh = self.decode_head
@@ -454,7 +471,7 @@ class EncoderDecoder(BaseSegmentor):
                 self.losses.update(self._auxiliary_head_forward_train(f_sup, sup['img_metas'], sup['gt_semantic_seg']))
             self.losses.update(loss_decode_sup)
         else:
-            self._fused_heads_sequential(sup, stu, simg, outs, f_sup, f_mask, ns, nu, teacher_info)
+            self._fused_heads_sequential(sup, stu, simg, outs, f_sup, f_mask, ns, nu, teacher_info, aug)
             return
         if self.iter_unsup_start != 0:
             if self.current_iter > self.iter_unsup_start:
@@ -462,7 +479,7 @@ class EncoderDecoder(BaseSegmentor):
         else:
             self.losses.update(unsup_loss)
 
-    def _fused_heads_sequential(self, sup, stu, simg, outs, f_sup, f_mask, ns, nu, teacher_info):
+    def _fused_heads_sequential(self, sup, stu, simg, outs, f_sup, f_mask, ns, nu, teacher_info, aug=None):
         # supervised heads
         loss_decode_sup = self._decode_head_forward_train(f_sup, sup['img_metas'], sup['gt_semantic_seg'])
         if self.with_auxiliary_head:
@@ -479,7 +496,9 @@ class EncoderDecoder(BaseSegmentor):
             if self.attn_mask_seperate_head:
                 loss_unsup['loss_seg_unsup_attn_mask'] = self.compute_pseudo_loss(student_info, teacher_info)['loss_seg_unsup'] * 0.5
                 student_info['backbone_feature'] = self.backbone.split_taps(outs, ns + nu, ns + 2 * nu)
-            losses = self.compute_pseudo_loss(student_info, teacher_info)
+            losses = self.compute_pseudo_loss(student_info, teacher_info, aug=aug, ncr=self.negative_class_ranking)
+            if self.negative_class_ranking:
+                loss_unsup['loss_ncr_unsup'] = losses['loss_ncr_unsup'] * 0.5
             loss_unsup['loss_seg_unsup'] = losses['loss_seg_unsup'] * self.fdrop_loss_weight
             unsup_loss = weighted_loss(loss_unsup, weight=self.unsup_weight)
         if self.iter_unsup_start != 0:
@@ -509,8 +528,17 @@ class EncoderDecoder(BaseSegmentor):
             student_info['backbone_feature'] = feat
             with on_head_stream(feat[-1].device, 'decode'):      # the scaling stays on the stream of the loss it scales
                 loss_unsup['loss_seg_unsup_attn_mask'] = self.compute_pseudo_loss(student_info, teacher_info)['loss_seg_unsup'] * 0.5
+            aug = None
+            if self.use_PatchShuffle_w_Cutmix:
+                student_info['img'], aug = self._strong_augment(student_info['img'], teacher_info)
             feat = self.extract_feat(student_info['img'])
             student_info['backbone_feature'] = feat
+            with on_head_stream(student_info['img'].device, 'decode'):
+                losses = self.compute_pseudo_loss(student_info, teacher_info, aug=aug, ncr=self.negative_class_ranking)
+                if self.negative_class_ranking:
+                    loss_unsup['loss_ncr_unsup'] = losses['loss_ncr_unsup'] * 0.5
+                loss_unsup['loss_seg_unsup'] = losses['loss_seg_unsup'] * self.fdrop_loss_weight
+            return loss_unsup
         elif self.plain_mt_pseudo_loss:
             attn_mask = self._conf_to_patch_u(teacher_info['conf_mask'])
             feat = self.extract_feat(student_info['img'], attn_mask=attn_mask, attn_mask_weight=self.attn_mask_weight,
@@ -521,10 +549,9 @@ class EncoderDecoder(BaseSegmentor):
             # side effect (backbone only, no BN), so it is skipped here.
             return loss_unsup
 
-        if self.attn_mask_seperate_head or self.plain_mt_pseudo_loss:
-            with on_head_stream(student_info['img'].device, 'decode'):
-                losses = self.compute_pseudo_loss(student_info, teacher_info)
-                loss_unsup['loss_seg_unsup'] = losses['loss_seg_unsup'] * self.fdrop_loss_weight
+        with on_head_stream(student_info['img'].device, 'decode'):
+            losses = self.compute_pseudo_loss(student_info, teacher_info)
+            loss_unsup['loss_seg_unsup'] = losses['loss_seg_unsup'] * self.fdrop_loss_weight
         return loss_unsup
 
     def extract_teacher_info_ema(self, img, img_metas, unsup_confidence=None):
@@ -541,12 +568,47 @@ class EncoderDecoder(BaseSegmentor):
         return dict(backbone_feature=feat, seg_logits_lowres=logits_lo, hard_seg_label=label, conf_mask=conf,
                     conf_count=cnt, img_metas=img_metas)
 
-    def compute_pseudo_loss(self, student_info, teacher_info):
-        """encoder_decoder.py:906-934 (hard labels): mean over ALL pixels of CE(student logits, pseudo labels with
-        ignore 255); mask_ratio = sum(conf) / numel (kept on the device in self.last_mask_ratio)."""
+    def _strong_augment(self, simg, teacher_info):
+        """use_PatchShuffle_w_Cutmix (encoder_decoder.py:633-638): CutMix between the student images (and between their
+        pseudo-labels; conf_mask and the teacher logits stay as they are), then PatchShuffle of the images in blocks of
+        patchsize * PatchMix_N pixels.  The decisions come from the host generators in the reference's order
+        (augment.draw_strong_aug); the pixels move in one gather kernel.  Returns the augmented images and
+        dict(labels, maps): cut-mixed labels and the token un-shuffle maps the decode head applies (decode_head.py:186-212)."""
+        from . import augment as A
+        Bn, _, H, W = simg.shape
+        block = self.patchsize * self.PatchMix_N
+        if H != W or H % block:
+            raise S4FError(f'PatchShuffle needs square images of whole {block}-pixel blocks, got {H}x{W}')
+        boxes, perms = A.draw_strong_aug(Bn, H, W, self.strong_aug_prob, self.cutout_area, self.patchmix_ratio, block)
+        dev = simg.device
+        box_d = torch.from_numpy(boxes).to(dev, non_blocking=True)
+        perm_d = torch.from_numpy(perms).to(dev, non_blocking=True)
+        simg = simg.contiguous()
+        out = torch.empty_like(simg)
+        K.mix_images(simg, out, box_d.reshape(-1), perm_d.reshape(-1), block)
+        labels = teacher_info['hard_seg_label']
+        if boxes.any():
+            mixed = torch.empty_like(labels)
+            K.cutmix_labels(labels, mixed, box_d.reshape(-1))
+            labels = mixed
+        maps = None
+        if (perms != np.arange(perms.shape[1], dtype=perms.dtype)[None]).any():
+            fwd, bwd = A.token_unshuffle_maps(perms, H // self.patchsize, self.PatchMix_N)
+            maps = (torch.from_numpy(fwd).to(dev, non_blocking=True), torch.from_numpy(bwd).to(dev, non_blocking=True))
+        self.last_aug = dict(boxes=boxes, perms=perms)
+        return out, dict(labels=labels, maps=maps)
+
+    def compute_pseudo_loss(self, student_info, teacher_info, aug=None, ncr=False):
+        """encoder_decoder.py:906-954 (hard labels): mean over ALL pixels of CE(student logits, pseudo labels with
+        ignore 255); mask_ratio = sum(conf) / numel (kept on the device in self.last_mask_ratio).  aug: the cut-mixed labels
+        and the token un-shuffle of a strongly augmented student batch; ncr: add 'loss_ncr_unsup' (mode 'unsup_only')
+        against the teacher's logits (the reference also evaluates it on the masked pass and drops the value: skipped)."""
         with on_head_stream(teacher_info['hard_seg_label'].device, 'decode'):
-            loss = self.decode_head.fused_loss(student_info['backbone_feature'], teacher_info['hard_seg_label'], 1.0)
-            out = {'loss_seg_unsup': loss}
+            labels = teacher_info['hard_seg_label'] if aug is None else aug['labels']
+            res = self.decode_head.fused_loss(student_info['backbone_feature'], labels, 1.0,
+                                              ncr_teacher_lo=teacher_info['seg_logits_lowres'] if ncr else None,
+                                              token_maps=None if aug is None else aug['maps'])
+            out = {'loss_seg_unsup': res[0], 'loss_ncr_unsup': res[1]} if ncr else {'loss_seg_unsup': res}
             if self.unsup_confidence != 0:
                 numel = teacher_info['hard_seg_label'].numel()
                 self.last_mask_ratio = teacher_info['conf_count'].to(torch.float32) / numel

@@ -387,6 +387,29 @@ class LayerFn(Function):
         return (g0,) + (None,) * (6 + 12)
 
 
+# ============================================================================================== token un-shuffle
+class TokenGatherFn(Function):
+    """out.rows = tokens.rows[fwd]  over the flattened [B * (T + 1), E] token tensor: the decode head's un-shuffle of a
+    patch-shuffled image (decode_head.py:186-212; augment.token_unshuffle_maps).  Backward = the gather with the inverse map."""
+
+    @staticmethod
+    def forward(ctx, tokens, fwd, bwd):
+        tokens = tokens.contiguous()
+        Bn, ntok, E = tokens.shape
+        out = torch.empty_like(tokens)
+        K.gather_rows(tokens, out, fwd, Bn * ntok, E)
+        ctx.bwd = bwd
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        Bn, ntok, E = g.shape
+        out = torch.empty_like(g)
+        K.gather_rows(g, out, ctx.bwd, Bn * ntok, E)
+        return out, None, None
+
+
 # ============================================================================================== SETR-PUP head
 def _world():
     return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
@@ -591,10 +614,13 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
 
 
 class HeadLossFn(Function):
-    """loss = loss_weight * mean_all_pixels CE(up_s(logits_lo), labels; ignore 255)   (Q5)"""
+    """loss = loss_weight * mean_all_pixels CE(up_s(logits_lo), labels; ignore 255)   (Q5)
+    With ncr_lo (the teacher's low-resolution logits of the same images): returns (loss, loss_ncr), loss_ncr = the negative
+    class ranking term of encoder_decoder.py:936-954 (mode 'unsup_only') on the SAME student logits; the backward adds both
+    gradients on the low-resolution logits before the head's backward runs once."""
 
     @staticmethod
-    def forward(ctx, tokens, labels_u8, loss_weight, hp, store, *prm):
+    def forward(ctx, tokens, labels_u8, loss_weight, hp, store, ncr_lo, *prm):
         need_grad = any(ctx.needs_input_grad)
         logits, (Bn, h, w), sv = head_forward(tokens, hp, store, training=hp['training'], save=need_grad)
         s = hp['up_scale']
@@ -616,10 +642,16 @@ class HeadLossFn(Function):
             # is final - and handed to the gradient reducer - when the last of those calls has run its backward
             ctx.range = store.range_of(prm)
             store.range_acquire(ctx.range)
-        return (loss_sum * k).reshape(())
+            ctx.ncr_lo = ncr_lo
+        loss = (loss_sum * k).reshape(())
+        if ncr_lo is None:
+            return loss
+        ncr_sum = zeros_small(1, tokens.device)
+        K.ncr_fwd(logits, ncr_lo, labels_u8, ncr_sum, Bn, h, w, hp['num_classes'], LOGIT_LD, s)
+        return loss, (ncr_sum * (1.0 / float(Bn * H * W))).reshape(())
 
     @staticmethod
-    def backward(ctx, dloss):
+    def backward(ctx, dloss, dncr=None):
         sv, hp, store = ctx.sv, ctx.hp, ctx.store
         labels, k, Bn, h, w, s = ctx.meta
         code = store.dtype
@@ -630,13 +662,18 @@ class HeadLossFn(Function):
         K.upce_bwd(logits, labels, k, dlo, dlo_t, Bn, h, w, hp['num_classes'], LOGIT_LD, s, code, hp['ignore_index'],
                    gscale_dev=gdev, lse=ctx.lse)
         ctx.lse = None
+        if ctx.ncr_lo is not None and dncr is not None:
+            ndev = dncr.detach().reshape(1).to(torch.float32).contiguous()
+            K.ncr_bwd(logits, ctx.ncr_lo, labels, 1.0 / float(Bn * h * s * w * s), dlo, dlo_t, Bn, h, w, hp['num_classes'], LOGIT_LD,
+                      s, code, gscale_dev=ndev)
+        ctx.ncr_lo = None
         dtok = head_backward(dlo, dlo_t if dlo_t is not None else dlo, sv, hp, store)
         if ctx.consumer is not None:
             dtok.record_stream(ctx.consumer)          # allocated on the head's stream, read by the backbone's
         ctx.sv = None
         store.node_done()
         store.range_release(ctx.range)
-        return (dtok, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 5)
+        return (dtok, None, None, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 6)
 
 
 class MultiHeadLossFn(Function):

@@ -14,7 +14,8 @@ from ._lib import (ACT_GELU, ACT_GELU_BWD, ACT_NONE, BF16, F32, OP_K, OP_K_CONV,
 __all__ = ['gemm', 'wgrad_grouped', 'transpose_many', 'cast', 'cast_back', 'im2col_patch16', 'cls_pos', 'tokens_bwd', 'colsum', 'layernorm_fwd',
            'layernorm_bwd', 'add_f32', 'attention_fwd', 'attention_bwd', 'bn_stats', 'bn_finalize',
            'bn_relu_up_fwd', 'bn_relu_up_bwd', 'bn_bwd_apply', 'bn_param_grads', 'upce_fwd', 'upce_bwd',
-           'up_pseudo_label', 'up_logits_nchw', 'ce_fwd', 'ce_bwd', 'ema', 'sgd_momentum']
+           'up_pseudo_label', 'up_logits_nchw', 'ce_fwd', 'ce_bwd', 'ema', 'sgd_momentum', 'ncr_fwd', 'ncr_bwd', 'mix_images',
+           'cutmix_labels', 'gather_rows']
 
 
 def _need(t, n, what):
@@ -487,6 +488,55 @@ def up_logits_nchw(logits_lo, out, B, h, w, C, ldc, s):
     _chk_f32(logits_lo, 'up_logits lo'); _need(logits_lo, B * h * w * ldc, 'up_logits lo')
     _chk_f32(out, 'up_logits out'); _need(out, B * C * h * s * w * s, 'up_logits out')
     call('s4f_up_logits_nchw', p(logits_lo), p(out), B, h, w, C, ldc, s, stream())
+
+
+def ncr_fwd(student_lo, teacher_lo, labels, loss_sum, B, h, w, C, ldc, s):
+    for t, wh in ((student_lo, 'student'), (teacher_lo, 'teacher')):
+        _chk_f32(t, f'ncr {wh} logits'); _need(t, B * h * w * ldc, f'ncr {wh} logits')
+    _chk_u8(labels, B * h * s * w * s, 'ncr labels'); _chk_f32(loss_sum, 'ncr loss'); _need(loss_sum, 1, 'ncr loss')
+    call('s4f_ncr_fwd', p(student_lo), p(teacher_lo), p(labels), p(loss_sum), B, h, w, C, ldc, s, stream())
+
+
+def ncr_bwd(student_lo, teacher_lo, labels, gscale, dlo, dlo_t, B, h, w, C, ldc, s, dtype, gscale_dev=None):
+    """dlo (fp32, already holding the CE gradient) += gscale * gscale_dev * d ncr / d student_lo; dlo_t = rounded sum"""
+    for t, wh in ((student_lo, 'student'), (teacher_lo, 'teacher'), (dlo, 'dlo')):
+        _chk_f32(t, f'ncr_bwd {wh}'); _need(t, B * h * w * ldc, f'ncr_bwd {wh}')
+    _chk_u8(labels, B * h * s * w * s, 'ncr_bwd labels')
+    _chk_dtype(dlo_t, dtype, 'ncr_bwd dlo_t'); _need(dlo_t, B * h * w * ldc if dlo_t is not None else 0, 'ncr_bwd dlo_t')
+    _chk_f32(gscale_dev, 'ncr_bwd gscale_dev'); _need(gscale_dev, 1 if gscale_dev is not None else 0, 'ncr_bwd gscale_dev')
+    call('s4f_ncr_bwd', p(student_lo), p(teacher_lo), p(labels), float(gscale), p(gscale_dev), p(dlo), p(dlo_t), B, h, w, C, ldc,
+         s, dtype, stream())
+
+
+def _chk_i32(t, n, what):
+    if t.dtype != torch.int32:
+        raise S4FError(f'{what}: must be int32')
+    _need(t, n, what)
+
+
+def mix_images(img, out, box, perm, block):
+    """out = PatchShuffle(CutMix(img)): box int32 [B, 4] (y0, y1, x0, x1), perm int32 [B, (H/block)^2]"""
+    B, C, H, W = img.shape
+    _chk_f32(img, 'mix_images img'); _chk_f32(out, 'mix_images out')
+    _need(img, B * C * H * W, 'mix_images img'); _need(out, B * C * H * W, 'mix_images out')
+    if H != W or H % block or block % 4:
+        raise S4FError(f'mix_images: square images of whole blocks expected, got {H}x{W}, block {block}')
+    _chk_i32(box, 4 * B, 'mix_images box'); _chk_i32(perm, B * (H // block) ** 2, 'mix_images perm')
+    call('s4f_mix_images', p(img), p(out), p(box), p(perm), B, C, H, W, block, stream())
+
+
+def cutmix_labels(labels, out, box):
+    B, H, W = labels.shape
+    _chk_u8(labels, B * H * W, 'cutmix labels'); _chk_u8(out, B * H * W, 'cutmix out'); _chk_i32(box, 4 * B, 'cutmix box')
+    call('s4f_cutmix_labels', p(labels), p(out), p(box), B, H, W, stream())
+
+
+def gather_rows(src, out, row_map, rows, C):
+    _chk_f32(src, 'gather_rows src'); _chk_f32(out, 'gather_rows out')
+    _need(out, rows * C, 'gather_rows out'); _need(src, rows * C, 'gather_rows src'); _chk_i32(row_map, rows, 'gather_rows map')
+    if C % 4:
+        raise S4FError('gather_rows: C must be a multiple of 4')
+    call('s4f_gather_rows', p(src), p(out), p(row_map), rows, C, stream())
 
 
 def ce_fwd(logits, labels, class_weight, loss_elem, N, C, spatial, ignore_index):

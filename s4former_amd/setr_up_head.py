@@ -231,11 +231,18 @@ class SETRUPHead(BaseDecodeHead):
             logits, geom, _ = head_forward(tokens.detach(), (hp := self._hp(grid)), store, training=hp['training'], save=False)
         return logits, geom
 
-    def fused_loss(self, inputs, labels_u8, loss_weight):
+    def fused_loss(self, inputs, labels_u8, loss_weight, ncr_teacher_lo=None, token_maps=None):
+        """loss_weight * CE(mean over all pixels) of this head on `inputs`, as one fused node.
+        token_maps (fwd, bwd): un-shuffle the tokens of a patch-shuffled image first (forward(..., PatchMix_N, PatchMixIndex) of
+        the reference, decode_head.py:186-212, 242-249); ncr_teacher_lo: also return the negative-class-ranking loss against
+        the teacher's low-resolution logits -> (loss, loss_ncr)."""
         x = self._transform_inputs(inputs)
         store = self._ensure_store(x.device)
         tokens, grid = self._tokens_of(x)
-        return HeadLossFn.apply(tokens, labels_u8, loss_weight, self._hp(grid), store, *self._params())
+        if token_maps is not None:
+            from .functional import TokenGatherFn
+            tokens = TokenGatherFn.apply(tokens, token_maps[0], token_maps[1])
+        return HeadLossFn.apply(tokens, labels_u8, loss_weight, self._hp(grid), store, ncr_teacher_lo, *self._params())
 
     def _loss_labels(self, img_metas, gt_semantic_seg):
         if img_metas and 'PatchMix_N' in img_metas[0]:

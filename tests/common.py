@@ -110,6 +110,13 @@ def make_batch(seed, n_sup, n_unsup, img=64, num_classes=21, block=8, border=2):
     return imgs, gt, metas
 
 
+def seed_host_rng(seed):
+    """what tests/golden/make_golden.py did before every iteration of the reference: the "ours" augmentations (CutMix box,
+    PatchShuffle permutation) draw from numpy's and torch's global generators"""
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
 def sha(t):
     return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
 

@@ -7,6 +7,7 @@ regenerated from seeds on the GPU box (tests/common.py), so only outputs are sto
 
 Usage (build container):  python tests/golden/make_golden.py
 """
+import copy
 import json
 import os
 import sys
@@ -20,6 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
 from oracle import model as OM  # noqa: E402
+from oracle import ops as O  # noqa: E402
 from oracle import ref_harness as RH  # noqa: E402
 from tests import common as C  # noqa: E402
 
@@ -29,6 +31,10 @@ SCENARIOS = {
     'mt_literal': (dict(unsup_weight=1.0), 2, 2, 0.01, 60.0),
     'mt_pasa': (dict(unsup_weight=1.0, attn_mask_seperate_head=True, attn_mask_weight=5, adaptive_attn_mask=True), 2, 2,
                 0.001, 60.0),
+    # configs/setr/..._MT_w_ours.py:236-256 on the tiny model (PatchMix_N = 2: 32-pixel blocks of the 64-pixel crops)
+    'mt_ours': (dict(unsup_weight=1.0, attn_mask_seperate_head=True, attn_mask_weight=5, adaptive_attn_mask=True,
+                     use_PatchShuffle_w_Cutmix=True, PatchMix_N=2, negative_class_ranking=True,
+                     negative_class_ranking_mode='unsup_only'), 2, 2, 0.001, 60.0),
 }
 SEED_W, SEED_B = 1999, 2024
 RELU_MARGIN = 2e-6     # iteration 0 of a fixture must not decide any ReLU by less than this (see relu_margin below)
@@ -62,7 +68,7 @@ def grad_sample(g, ns=NS):
     return f[::step][:ns].clone()
 
 
-def fp64_grad_samples(cfg, seed_w, gain, batch, ns=NS):
+def fp64_grad_samples(cfg, seed_w, gain, batch, ns=NS, rng_seed=0):
     """iteration 0 of the reference evaluated in float64 (same float32 weights and inputs, widened): what the reference's own
     fp32 gradients are a rounding of.  Returns {name: (samples float64, max |g|)}."""
     imgs, gt, metas = batch
@@ -76,7 +82,8 @@ def fp64_grad_samples(cfg, seed_w, gain, batch, ns=NS):
         with tempfile.TemporaryDirectory() as td:
             os.chdir(td)
             try:
-                losses = ref.forward_train(imgs.double(), metas, gt_semantic_seg=gt, iter=0)
+                seed_host_rng(rng_seed)
+                losses = ref.forward_train(imgs.double(), copy.deepcopy(metas), gt_semantic_seg=gt, iter=0)
             finally:
                 os.chdir(cwd)
         sum(v.mean() for k, v in losses.items() if 'loss' in k).backward()
@@ -86,12 +93,20 @@ def fp64_grad_samples(cfg, seed_w, gain, batch, ns=NS):
             for n, p in ref.named_parameters() if p.grad is not None}
 
 
-def run_steps(model, fwd, params_named, opt, set_lr, batches, n_iters=2):
+def seed_host_rng(seed):
+    """the in-model augmentations draw from numpy's and torch's GLOBAL generators (generate_unsup_data.py): every iteration
+    of every implementation starts from the same state"""
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def run_steps(model, fwd, params_named, opt, set_lr, batches, n_iters=2, seed_b=0):
     rec = []
     for it in range(n_iters):
         imgs, gt, metas = batches[it]
         set_lr(opt, it)
         opt.zero_grad()
+        seed_host_rng(seed_b + it)
         losses = fwd(imgs, gt, metas, it)
         loss = sum(v.mean() for k, v in losses.items() if 'loss' in k)
         loss.backward()
@@ -118,11 +133,19 @@ def main():
             probe.train()
             C.load_filled(probe, SEED_W, gain)
             b0 = C.make_batch(seed_b, n_sup, n_unsup)
+            if flags.get('use_PatchShuffle_w_Cutmix'):
+                # the fixture must exercise both augmentations at iteration 0
+                seed_host_rng(seed_b)
+                boxes, perms = O.draw_strong_aug(n_unsup, (64, 64), 0.5, 2, 0.5, 16 * flags['PatchMix_N'])
+                if not any(b[1] > b[0] for b in boxes) or not any(p.tolist() != sorted(p.tolist()) for p in perms):
+                    seed_b += 10
+                    continue
+            seed_host_rng(seed_b)
             cwd = os.getcwd()
             with tempfile.TemporaryDirectory() as td:
                 os.chdir(td)
                 try:
-                    margin = relu_margin(probe, lambda: probe.forward_train(b0[0], b0[2], gt_semantic_seg=b0[1], iter=0))
+                    margin = relu_margin(probe, lambda: probe.forward_train(b0[0], copy.deepcopy(b0[2]), gt_semantic_seg=b0[1], iter=0))
                 finally:
                     os.chdir(cwd)
             print(f'[{name}] batch seed {seed_b}: smallest |ReLU input| at iteration 0 = {margin:.2e}', flush=True)
@@ -138,11 +161,13 @@ def main():
         cwd = os.getcwd()
 
         def ref_fwd(imgs, gt, metas, it):
-            return ref.forward_train(imgs, metas, gt_semantic_seg=gt, iter=it)
+            # (the reference writes PatchMix_N / PatchMixIndex INTO the img_metas dicts: every call gets its own copy, as every
+            # iteration of a real run gets fresh metas from the data loader)
+            return ref.forward_train(imgs, copy.deepcopy(metas), gt_semantic_seg=gt, iter=it)
         with tempfile.TemporaryDirectory() as td:
             os.chdir(td)
             try:
-                rrec = run_steps(ref, ref_fwd, ref.named_parameters, ropt, OM.set_poly_lr, batches)
+                rrec = run_steps(ref, ref_fwd, ref.named_parameters, ropt, OM.set_poly_lr, batches, seed_b=seed_b)
             finally:
                 os.chdir(cwd)
         # ---------------- oracle
@@ -153,7 +178,7 @@ def main():
 
         def orc_fwd(imgs, gt, metas, it):
             return orc.forward_train(imgs, [m['tag'] for m in metas], gt)
-        orec = run_steps(orc, orc_fwd, orc.named_parameters, oopt, OM.set_poly_lr, batches)
+        orec = run_steps(orc, orc_fwd, orc.named_parameters, oopt, OM.set_poly_lr, batches, seed_b=seed_b)
         # ---------------- compare oracle vs reference
         # iteration 0 must agree to fp32 rounding; iteration 1 sits behind an SGD step (head lr up to 0.1) that
         # amplifies summation-order differences, so it gets a looser band.
@@ -194,7 +219,7 @@ def main():
             out[f'it{it}_gmax'] = np.array([rrec[it]['grad_max'][n] for n in rrec[it]['grad_norms']], dtype=np.float64)
         # the same iteration-0 gradients evaluated in float64: the tests bound the product's distance to THESE by a multiple of
         # the reference's own fp32 distance to them (its fp32 gradients are only good to ~5e-4 of a tensor's maximum)
-        g64 = fp64_grad_samples(cfg, SEED_W, gain, batches[0])
+        g64 = fp64_grad_samples(cfg, SEED_W, gain, batches[0], rng_seed=seed_b)
         gs64 = np.zeros((len(rrec[0]['grad_norms']), NS), dtype=np.float64)
         for i, n in enumerate(rrec[0]['grad_norms']):
             gs64[i, :g64[n][0].size] = g64[n][0]
@@ -211,7 +236,7 @@ def main():
             ref.set_eval(True)
             with torch.no_grad():
                 imgs, gt, metas = batches[1]
-                tinfo = ref.extract_teacher_info_ema(imgs[n_sup + n_unsup:], metas[n_sup + n_unsup:])
+                tinfo = ref.extract_teacher_info_ema(imgs[n_sup + n_unsup:], copy.deepcopy(metas[n_sup + n_unsup:]))
             ref.set_train(True)
             lab = tinfo['hard_seg_label'].clone()
             lab[tinfo['conf_mask'] == 0] = 255

@@ -60,6 +60,7 @@ def test_tiny_model_keys_match_oracle():
 @pytest.mark.parametrize('fn,lr,uw', [
     ('setr_deit-base_pup_bs_8_512x512_80k_pascal_1over16_split_classic_sup.py', 0.001, 0),
     ('setr_deit-base_pup_bs_8_512x512_80k_pascal_1over16_split_classic_semi_beta_1_th_0.95_MT.py', 0.01, 1.0),
+    ('setr_deit-base_pup_bs_8_512x512_80k_pascal_1over16_split_classic_semi_beta_1_th_0.95_MT_w_ours.py', 0.001, 1.0),
 ])
 def test_reference_configs_load_unchanged(fn, lr, uw):
     cfg = S.Config.fromfile(os.path.join(REF_CFG, fn))
@@ -70,6 +71,9 @@ def test_reference_configs_load_unchanged(fn, lr, uw):
     assert cfg.model.unsup_weight == uw and cfg.optimizer.lr == lr
     assert cfg.lr_config.policy == 'poly' and cfg.lr_config.power == 0.9 and cfg.lr_config.min_lr == 1e-4
     m = S.build_segmentor(cfg.model, train_cfg=cfg.get('train_cfg'), test_cfg=cfg.get('test_cfg'))
+    if fn.endswith('_w_ours.py'):      # the paper's method: PASA + CutMix / PatchShuffle + negative class ranking
+        assert m.attn_mask_seperate_head and m.adaptive_attn_mask and m.attn_mask_weight == 5
+        assert m.use_PatchShuffle_w_Cutmix and m.PatchMix_N == 8 and m.negative_class_ranking
     assert sum(p.numel() for p in m.parameters()) == 189430910
     assert sum(p.numel() for p in m.parameters() if p.requires_grad) == 99449961
     opt = S.build_optimizer(m, cfg.optimizer)
@@ -82,6 +86,29 @@ def test_reference_configs_load_unchanged(fn, lr, uw):
     assert abs(by['backbone.cls_token']['lr'] - O.poly_lr(lr, 40000, 80001)) < 1e-15
 
 
-def test_ours_config_flags_rejected_cleanly():
-    with pytest.raises(S.S4FError):
-        S.build_segmentor(C.tiny_model_cfg(use_PatchShuffle_w_Cutmix=True))
+def test_out_of_scope_flags_rejected_cleanly():
+    # (the flags of configs/setr/..._MT_w_ours.py are built; the other in-model augmentations / NCR modes are outside SURVEY §8)
+    for flags in (dict(use_CutMix=True), dict(use_ClassMix=True), dict(use_PatchShuffle=True), dict(unimatch=True),
+                  dict(negative_class_ranking=True, negative_class_ranking_mode='both', attn_mask_seperate_head=True),
+                  dict(use_PatchShuffle_w_Cutmix=True)):            # (needs attn_mask_seperate_head)
+        with pytest.raises(S.S4FError):
+            S.build_segmentor(C.tiny_model_cfg(**flags))
+
+
+def test_strong_augmentation_decisions_follow_the_reference_rng_order():
+    """augment.draw_strong_aug (product) == oracle.ops.draw_strong_aug (pinned to the reference by the mt_ours golden), and
+    the token un-shuffle maps == the restated _repatchmix_inputs, incl. their adjoint"""
+    import numpy as np
+    import torch
+    from s4former_amd import augment as A
+    for seed in range(6):
+        np.random.seed(seed); torch.manual_seed(seed)
+        b1, p1 = A.draw_strong_aug(3, 64, 64, 0.5, 2, 0.5, 32)
+        np.random.seed(seed); torch.manual_seed(seed)
+        b2, p2 = O.draw_strong_aug(3, (64, 64), 0.5, 2, 0.5, 32)
+        assert b1.tolist() == [list(b) for b in b2] and p1.tolist() == [p.tolist() for p in p2]
+        tok = torch.randn(3, 17, 8)
+        fwd, bwd = A.token_unshuffle_maps(p1, 4, 2)
+        got = tok.reshape(-1, 8)[torch.from_numpy(fwd).long()].reshape(3, 17, 8)
+        assert torch.equal(got[:, 1:], O.repatchmix_tokens(tok[:, 1:], p2, 2)) and torch.equal(got[:, 0], tok[:, 0])
+        assert torch.equal(got.reshape(-1, 8)[torch.from_numpy(bwd).long()].reshape(3, 17, 8), tok)

@@ -676,3 +676,82 @@ def test_gemm2_conv_modes(K, hint, Cin, Cout):
     K.gemm(dyh, xh, Cout, 9 * Cin, M, Cout, Cin, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV, out_f32=dw, ldo_f32=9 * Cin, atomic=True,
            splitk=3, conv=(B, H, W, Cin, 1), tile_hint=hint)
     check(dw.reshape(Cout, 3, 3, Cin), wr.grad.permute(0, 2, 3, 1), code, f'gemm2 conv wgrad hint {hint}', tol=3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ "ours" additions (§8f-1)
+@pytest.mark.parametrize('s', [1, 2, 4])
+def test_negative_class_ranking(K, s):
+    """encoder_decoder.py:936-954 (mode 'unsup_only'): loss and student-logit gradient vs the oracle, incl. ignored pixels
+    (label 255: no term) and the accumulation on top of an existing CE gradient"""
+    B, C, h, w, ldc = 2, 21, 12, 12, 32
+    H, W = h * s, w * s
+    slo, tlo = rnd(B, C, h, w, seed=11, scale=2.0), rnd(B, C, h, w, seed=12, scale=2.0)
+    lab = torch.randint(0, C, (B, H, W), generator=torch.Generator().manual_seed(13))
+    lab[:, :3] = 255
+    lab[0, 5, 5] = 0; lab[0, 5, 6] = C - 1                     # first / last class removed
+    sr = slo.clone().requires_grad_(True)
+    zs = O.upsample(sr, s) if s > 1 else sr
+    zt = O.upsample(tlo, s) if s > 1 else tlo
+    ref = O.ncr_unsup_only(zs, zt, lab)
+    ref.backward()
+    pack = lambda t: dev(torch.cat((to_nhwc(t), torch.zeros(B, h, w, ldc - C)), -1))
+    sd, td, ld = pack(slo), pack(tlo), dev(lab.to(torch.uint8))
+    ls = torch.zeros(1, device='cuda')
+    K.ncr_fwd(sd, td, ld, ls, B, h, w, C, ldc, s)
+    got = float(ls) / (B * H * W)
+    assert abs(got - float(ref)) <= 1e-5 * abs(float(ref)), (got, float(ref))
+    base = rnd(B, h, w, ldc, seed=14, scale=1e-3)
+    base[..., C:] = 0
+    for code in DTYPES:
+        dlo = dev(base.clone())
+        dlo_t = torch.empty(B, h, w, ldc, device='cuda', dtype=tdt(code)) if code == 1 else None
+        gdev = torch.full((1,), 0.5, device='cuda')
+        K.ncr_bwd(sd, td, ld, 2.0 / (B * H * W), dlo, dlo_t, B, h, w, C, ldc, s, code, gscale_dev=gdev)   # 2.0 * 0.5 = 1
+        want = base[..., :C] + to_nhwc(sr.grad)
+        check(dlo[..., :C], want, 0, f'NCR d student logits (s = {s})', tol=2e-5)
+        assert float(dlo[..., C:].abs().max()) == 0.0
+        if dlo_t is not None:
+            check(dlo_t[..., :C].float(), want, 1, 'NCR gradient, T copy', tol=1e-2)
+    # no confident pixel -> loss 0, gradient untouched
+    ls.zero_()
+    none = torch.full((B, H, W), 255, dtype=torch.uint8, device='cuda')
+    K.ncr_fwd(sd, td, none, ls, B, h, w, C, ldc, s)
+    assert float(ls) == 0.0
+    dlo = dev(base.clone())
+    K.ncr_bwd(sd, td, none, 1.0, dlo, None, B, h, w, C, ldc, s, 0)
+    assert torch.equal(dlo.cpu(), base)
+
+
+def test_cutmix_patchshuffle_gather(K):
+    """generate_unsup_cutmix_data + generate_unsup_patchmix_data (generate_unsup_data.py:400-453, 737-819) in one gather:
+    bit-exact (pure data movement), labels cut-mixed but not shuffled, token un-shuffle + adjoint"""
+    from s4former_amd import augment as A
+    B, H, block = 3, 64, 32
+    img = rnd(B, 3, H, H, seed=21)
+    lab = torch.randint(0, 21, (B, H, H), generator=torch.Generator().manual_seed(22)).to(torch.uint8)
+    for seed in range(5):
+        np.random.seed(seed); torch.manual_seed(seed)
+        boxes, perms = A.draw_strong_aug(B, H, H, 0.7, 2, 0.7, block)
+        ref_img, ref_lab = O.cutmix(img, lab, [tuple(b) for b in boxes.tolist()])
+        ref_img = O.patch_shuffle(ref_img, torch.from_numpy(perms), block)
+        out = torch.empty(B, 3, H, H, device='cuda')
+        box_d, perm_d = torch.from_numpy(boxes).cuda().reshape(-1), torch.from_numpy(perms).cuda().reshape(-1)
+        K.mix_images(dev(img), out, box_d, perm_d, block)
+        assert torch.equal(out.cpu(), ref_img), f'seed {seed}'
+        lo = torch.empty(B, H, H, device='cuda', dtype=torch.uint8)
+        K.cutmix_labels(dev(lab), lo, box_d)
+        assert torch.equal(lo.cpu(), ref_lab)
+    # token un-shuffle (PatchMix_N = 2 on a 4 x 4 patch grid) through the autograd node, and its adjoint
+    from s4former_amd.functional import TokenGatherFn
+    perms = np.stack([np.random.RandomState(s).permutation(4) for s in range(B)]).astype(np.int32)
+    fwd, bwd = A.token_unshuffle_maps(perms, 4, 2)
+    tok = rnd(B, 17, 64, seed=23)
+    t = dev(tok).requires_grad_(True)
+    out = TokenGatherFn.apply(t, torch.from_numpy(fwd).cuda(), torch.from_numpy(bwd).cuda())
+    assert torch.equal(out[:, 1:].detach().cpu(), O.repatchmix_tokens(tok[:, 1:], torch.from_numpy(perms), 2))
+    assert torch.equal(out[:, 0].detach().cpu(), tok[:, 0])
+    g = rnd(B, 17, 64, seed=24)
+    out.backward(dev(g))
+    tr = tok.clone().requires_grad_(True)
+    (O.repatchmix_tokens(tr[:, 1:], torch.from_numpy(perms), 2) * g[:, 1:]).sum().backward()
+    assert torch.equal(t.grad[:, 1:].cpu(), tr.grad[:, 1:]) and torch.equal(t.grad[:, 0].cpu(), g[:, 0])

@@ -15,7 +15,7 @@ from oracle import ref_harness as RH
 from tests import common as C
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
-SCENARIOS = ['sup', 'mt_literal', 'mt_pasa']
+SCENARIOS = ['sup', 'mt_literal', 'mt_pasa', 'mt_ours']
 
 
 def load_gold(name):
@@ -36,6 +36,7 @@ def run_oracle(meta):
         assert C.sha(imgs) == meta['input_sha'][it], 'deterministic input generator drifted'
         OM.set_poly_lr(opt, it)
         opt.zero_grad()
+        C.seed_host_rng(meta['seed_b'] + it)       # the in-model augmentations draw from numpy's / torch's global generators
         losses = orc.forward_train(imgs, [m['tag'] for m in metas], gt)
         loss, _ = orc.parse_losses(losses)
         loss.backward()

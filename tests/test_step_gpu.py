@@ -46,6 +46,7 @@ def run_product(model, opt, sched, meta, iters=2):
         imgs, gt, metas = C.make_batch(meta['seed_b'] + it, meta['n_sup'], meta['n_unsup'])
         sched.step(it)
         opt.zero_grad()
+        C.seed_host_rng(meta['seed_b'] + it)
         out = model.train_step(dict(img=imgs.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda()), opt, iter=it)
         out['loss'].backward()
         torch.cuda.synchronize()        # (also joins the side stream: device-wide)
@@ -57,7 +58,7 @@ def run_product(model, opt, sched, meta, iters=2):
     return rec
 
 
-@pytest.mark.parametrize('name', ['sup', 'mt_literal', 'mt_pasa'])
+@pytest.mark.parametrize('name', ['sup', 'mt_literal', 'mt_pasa', 'mt_ours'])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_step_vs_golden(name, dtype):
     z, meta = load_gold(name)
