@@ -5,6 +5,7 @@ CrossEntropyLoss, configs load unchanged).  Device side: libs4f_hip.so, hand-wri
 the C ABI of include/s4f.h.  There is no CPU fallback on the product path."""
 from . import runtime  # noqa: F401
 from ._lib import S4FError  # noqa: F401
+from .checkpoint import convert_mmcls_deit, load_checkpoint, resume, save_checkpoint  # noqa: F401
 from .config import Config  # noqa: F401
 from .registry import (BACKBONES, HEADS, LOSSES, MODELS, SEGMENTORS, build_backbone, build_head, build_loss,  # noqa: F401
                        build_segmentor)

@@ -199,15 +199,9 @@ class VisionTransformer(BaseModule):
     def init_weights(self):
         ck = self.init_cfg.get('checkpoint') if isinstance(self.init_cfg, dict) else None
         if isinstance(self.init_cfg, dict) and self.init_cfg.get('type') == 'Pretrained' and ck and os.path.exists(ck):
-            checkpoint = torch.load(ck, map_location='cpu')
-            state_dict = checkpoint['state_dict'] if 'state_dict' in checkpoint else checkpoint
-            if 'pos_embed' in state_dict and self.pos_embed.shape != state_dict['pos_embed'].shape:
-                h, w = self.img_size
-                pos_size = int(math.sqrt(state_dict['pos_embed'].shape[1] - 1))
-                state_dict['pos_embed'] = self.resize_pos_embed(
-                    state_dict['pos_embed'], (h // self.patch_size, w // self.patch_size), (pos_size, pos_size),
-                    self.interpolate_mode, self.no_pos_embed)
-            self.load_state_dict(state_dict, strict=False)
+            # vit.py:369-393 (+ the README's mmcls key mapping when the file still has mmcls' names: checkpoint.py)
+            from .checkpoint import load_backbone_pretrained
+            load_backbone_pretrained(self, ck, convert='auto', strict=False)
             return
         if isinstance(self.init_cfg, dict) and self.init_cfg.get('type') == 'Pretrained':
             # the reference raises in CheckpointLoader.load_checkpoint; a silent random initialisation of student and teacher
