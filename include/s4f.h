@@ -226,6 +226,22 @@ int s4f_cutmix_labels(const uint8_t* labels, uint8_t* out, const int* box, int B
 /* out[r, :] = src[map[r], :]  (fp32 rows of C floats): the token un-shuffle of decode_head.py:186-212 and its adjoint */
 int s4f_gather_rows(const float* src, float* out, const int* map, int64_t rows, int C, s4f_stream stream);
 
+/* ---- evaluation path -----------------------------------------------------------------------------------
+ * mmseg.ops.resize (ops/wrappers.py:8-51) = F.interpolate(size, 'bilinear', align_corners) on fp32 NCHW planes.  The input
+ * is a window (ih x iw) of a larger plane (strides in elements): "remove padding area" + rescale to ori_shape
+ * (segmentors/encoder_decoder.py:1127-1147) in one pass.  out: dense [planes, oh, ow]. */
+int s4f_resize_bilinear_nchw(const float* in, float* out, int64_t planes, int ih, int iw, int64_t in_plane_stride,
+                             int64_t in_row_stride, int oh, int ow, int align_corners, s4f_stream stream);
+/* F.softmax(logits, dim=1) -> optional flip back (1 horizontal, 2 vertical: output.flip of encoder_decoder.py:1195-1202) ->
+ * prob (optional, NCHW), label = argmax over classes (uint8, first index on ties), pmax (optional) = its probability.
+ * raw != 0: the input already holds probabilities (aug_test's mean over augmentations): no softmax, arg-max only. */
+int s4f_softmax_argmax_nchw(const float* logits, float* prob, uint8_t* label, float* pmax, int B, int C, int H, int W, int flip,
+                            int raw, s4f_stream stream);
+/* intersect_and_union (core/evaluation/metrics.py:26-85): counts[0..C) += intersect, [C..2C) += prediction, [2C..3C) += label
+ * pixel counts over the n pixels whose label != ignore_index (uint64 accumulators, exact). */
+int s4f_confusion_counts(const uint8_t* pred, const uint8_t* label, int64_t n, int num_classes, int ignore_index,
+                         unsigned long long* counts, s4f_stream stream);
+
 /* Stand-alone CrossEntropyLoss on NCHW / [N,C] fp32 logits (cross_entropy_loss.py:12-63): per-element loss
  * (0 where ignored), optional class weights; spatial = H*W (1 for [N,C]). */
 int s4f_ce_fwd(const float* logits, const int64_t* labels, const float* class_weight, float* loss_elem, int64_t N,

@@ -182,6 +182,20 @@ class OracleSegmentor(nn.Module):
             self.backbone_ema.train(); self.decode_head_ema.train()
         return dict(seg_logits=seg_logits, hard_seg_label=label, conf_mask=conf)
 
+    def simple_test(self, img, img_shape, ori_shape, flip=None, ema=False):
+        """encoder_decoder.py:265-295, 1118-1223 with the intended semantics of mode='whole' (Q8): eval-mode network, logits at
+        the input size, then ops.whole_inference_post.  -> (prob, label)"""
+        bb, hd = (self.backbone_ema, self.decode_head_ema) if ema else (self.backbone, self.decode_head)
+        was = self.training
+        self.eval()
+        with torch.no_grad():
+            out = hd(bb(img))
+            if tuple(out.shape[2:]) != tuple(img.shape[2:]):
+                out = O.resize(out, img.shape[2:], False)
+            res = O.whole_inference_post(out, img_shape, ori_shape, flip, False)
+        self.train(was)
+        return res
+
     def compute_pseudo_loss(self, feat, tinfo, patchmix_n=0, perms=None):
         """encoder_decoder.py:906-954 (NCR: mode 'unsup_only')"""
         pred = self.decode_head(feat, patchmix_n, perms)

@@ -236,3 +236,53 @@ def ncr_unsup_only(student_logits, teacher_logits, hard_label):
         tc = torch.cat((t[m][:, :c], t[m][:, c + 1:]), dim=1)
         loss = loss + torch.sum(pdist(F.softmax(sc, dim=1), F.softmax(tc, dim=1)))
     return loss / (B * H * W)
+
+
+# ---------------------------------------------------------------------------------------------- evaluation path (§8f-2)
+def resize(x, size, align_corners=False):
+    """mmseg.ops.resize (ops/wrappers.py:8-51) with mode='bilinear'"""
+    return F.interpolate(x, tuple(int(s) for s in size), None, 'bilinear', align_corners)
+
+
+def whole_inference_post(seg_logit, img_shape, ori_shape, flip=None, align_corners=False):
+    """whole_inference + inference + simple_test after the network (encoder_decoder.py:1127-1147, 1193-1216): remove the padding
+    area, rescale to ori_shape, softmax, flip back, arg-max.  -> (prob [B, C, H, W], label int64 [B, H, W])"""
+    seg_logit = seg_logit[:, :, :img_shape[0], :img_shape[1]]
+    seg_logit = resize(seg_logit, ori_shape[:2], align_corners)
+    out = F.softmax(seg_logit, dim=1)
+    if flip == 'horizontal':
+        out = out.flip(dims=(3,))
+    elif flip == 'vertical':
+        out = out.flip(dims=(2,))
+    return out, out.argmax(dim=1)
+
+
+def intersect_and_union(pred_label, label, num_classes, ignore_index, label_map=None, reduce_zero_label=False):
+    """core/evaluation/metrics.py:26-85 (array inputs): three torch.histc passes over the non-ignored pixels"""
+    pred_label = torch.as_tensor(pred_label).clone()
+    label = torch.as_tensor(label).clone()
+    if label_map:
+        src = label.clone()
+        for old_id, new_id in label_map.items():
+            label[src == old_id] = new_id
+    if reduce_zero_label:
+        label[label == 0] = 255
+        label = label - 1
+        label[label == 254] = 255
+    mask = label != ignore_index
+    pred_label, label = pred_label[mask], label[mask]
+    intersect = pred_label[pred_label == label]
+    ai = torch.histc(intersect.float(), bins=num_classes, min=0, max=num_classes - 1)
+    ap = torch.histc(pred_label.float(), bins=num_classes, min=0, max=num_classes - 1)
+    al = torch.histc(label.float(), bins=num_classes, min=0, max=num_classes - 1)
+    return ai, ap + al - ai, ap, al
+
+
+def mean_iou(results, gt_seg_maps, num_classes, ignore_index, reduce_zero_label=False):
+    """metrics.py:88-166, 330-365: totals in float64, aAcc / IoU / Acc"""
+    tot = [torch.zeros(num_classes, dtype=torch.float64) for _ in range(4)]
+    for r, g in zip(results, gt_seg_maps):
+        for t, a in zip(tot, intersect_and_union(r, g, num_classes, ignore_index, None, reduce_zero_label)):
+            t += a
+    ai, au, ap, al = tot
+    return dict(aAcc=(ai.sum() / al.sum()).numpy(), IoU=(ai / au).numpy(), Acc=(ai / al).numpy()), tot

@@ -85,9 +85,29 @@ class BaseSegmentor(BaseModule):
         return hasattr(self, 'decode_head') and self.decode_head is not None
 
     def forward(self, img, img_metas, return_loss=True, **kwargs):
+        """base.py:108-121"""
         if return_loss:
             return self.forward_train(img, img_metas, **kwargs)
-        raise S4FError('inference entry points are outside the training hot path (SURVEY §8f-2, Q8)')
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """base.py:70-106: imgs / img_metas are lists over test-time augmentations"""
+        for var, name in [(imgs, 'imgs'), (img_metas, 'img_metas')]:
+            if not isinstance(var, list):
+                raise TypeError(f'{name} must be a list, but got {type(var)}')
+        num_augs = len(imgs)
+        if num_augs != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        for img_meta in img_metas:
+            ori_shapes = [_['ori_shape'] for _ in img_meta]
+            assert all(shape == ori_shapes[0] for shape in ori_shapes)
+            img_shapes = [_['img_shape'] for _ in img_meta]
+            assert all(shape == img_shapes[0] for shape in img_shapes)
+            pad_shapes = [_['pad_shape'] for _ in img_meta]
+            assert all(shape == pad_shapes[0] for shape in pad_shapes)
+        if num_augs == 1:
+            return self.simple_test(imgs[0], img_metas[0], **kwargs)
+        return self.aug_test(imgs, img_metas, **kwargs)
 
     def train_step(self, data_batch, optimizer, **kwargs):
         """base.py:155-206 without the per-iteration debug dumps to the CWD (Q6)."""
@@ -134,7 +154,7 @@ _UNSUP_STREAM = os.environ.get('S4F_UNSUP_STREAM', 'decode')    # experiment: 'd
 _UNSUPPORTED_TRUE = ('sup_ema', 'attn_frozen', 'sup_ClassMix', 'sup_cutmix', 'unsup_soft', 'use_CutMix', 'use_CutOut',
                      'use_ClassMix', 'mix_with_labeled', 'patchwise', 'use_PatchShuffle', 'use_PatchShuffle_w_Classmix',
                      'no_pos_embed', 'avg_pos_emd', 'duplicate_pos_emd', 'attn_mask_w_fdrop',
-                     'use_fdrop', 'unimatch', 'use_cutmix_adaptive', 'ema_test')
+                     'use_fdrop', 'unimatch', 'use_cutmix_adaptive')
 
 
 @SEGMENTORS.register_module()
@@ -190,6 +210,7 @@ class EncoderDecoder(BaseSegmentor):
         self.use_PatchShuffle_w_Cutmix, self.patchmix_ratio = use_PatchShuffle_w_Cutmix, patchmix_ratio
         self.strong_aug_prob, self.cutout_area = strong_aug_prob, cutout_area
         self.negative_class_ranking = negative_class_ranking
+        self.ema_test = ema_test
         self.with_auxiliary_head_ema = False
         if self.ema:
             if self.momentum_backbone != self.momentum_head:
@@ -321,6 +342,79 @@ class EncoderDecoder(BaseSegmentor):
         default: in the one-GPU rehearsal (no network latency) the interleaved large tensors cost 0.36 ms more than the
         saved round trips give back; to be re-measured on a multi-GPU node."""
         return os.environ.get('S4F_DECODE_LOCKSTEP', '0') == '1' and hasattr(type(self.decode_head), 'fused_losses_lockstep')
+
+    # ------------------------------------------------------------------ evaluation (SURVEY §8f-2)
+    # Reference: encoder_decoder.py:265-333, 1118-1231 with the intended semantics of its `whole` mode (as written,
+    # whole_inference calls encode_decode without the positional `adaptive_attn_mask` it requires - Q8 - and raises):
+    # backbone -> decode head (eval-mode BN) -> logits at the input size -> crop the padding, rescale to ori_shape ->
+    # softmax -> flip back -> argmax.  All tensor work is in HIP kernels (head logits, kernels.resize_bilinear,
+    # kernels.softmax_argmax); nothing here runs under autograd.
+    def _decode_head_forward_test(self, x, img_metas):
+        return self.decode_head.forward_test(x, img_metas, self.test_cfg)
+
+    def _decode_head_forward_test_ema(self, x, img_metas):
+        return self.decode_head_ema.forward_test(x, img_metas, self.test_cfg)
+
+    def encode_decode(self, img, img_metas):
+        """encoder_decoder.py:265-295: logits [B, C, H, W] of the student at the size of `img`"""
+        with torch.no_grad():
+            self.ensure_engine(img.device)
+            out = self._decode_head_forward_test(self.extract_feat(img), img_metas)
+            if tuple(out.shape[2:]) != tuple(img.shape[2:]):
+                out = K.resize_bilinear(out, img.shape[2:], self.align_corners)
+        return out
+
+    def encode_decode_ema(self, img, img_metas):
+        """encoder_decoder.py:297-307: the same through the EMA teacher (ema_test=True)"""
+        with torch.no_grad():
+            self.ensure_engine(img.device)
+            out = self._decode_head_forward_test_ema(self.extract_feat_ema(img), img_metas)
+            if tuple(out.shape[2:]) != tuple(img.shape[2:]):
+                out = K.resize_bilinear(out, img.shape[2:], self.align_corners)
+        return out
+
+    def whole_inference(self, img, img_meta, rescale):
+        """encoder_decoder.py:1118-1147"""
+        seg_logit = self.encode_decode_ema(img, img_meta) if self.ema_test else self.encode_decode(img, img_meta)
+        if rescale:
+            resize_shape = img_meta[0]['img_shape'][:2]          # remove padding area: read only this window
+            size = img_meta[0]['ori_shape'][:2]
+            seg_logit = K.resize_bilinear(seg_logit, size, self.align_corners, window=resize_shape)
+        return seg_logit
+
+    def slide_inference(self, img, img_meta, rescale):
+        raise S4FError("test_cfg.mode='slide' is not built: the SETR configs evaluate with mode='whole' (configs/setr/*:251)")
+
+    def inference(self, img, img_meta, rescale, return_labels=False):
+        """encoder_decoder.py:1174-1203 -> softmax probabilities [B, C, H, W], flipped back when the test image was flipped
+        (return_labels=True: also the arg-max labels [B, H, W] uint8 of the same pass)"""
+        mode = (self.test_cfg or {}).get('mode', 'whole') if isinstance(self.test_cfg, dict) else self.test_cfg.mode
+        assert mode in ['slide', 'whole']
+        ori_shape = img_meta[0]['ori_shape']
+        assert all(_['ori_shape'] == ori_shape for _ in img_meta)
+        seg_logit = self.slide_inference(img, img_meta, rescale) if mode == 'slide' else self.whole_inference(img, img_meta, rescale)
+        flip = 0
+        if img_meta[0].get('flip', False):
+            flip_direction = img_meta[0]['flip_direction']
+            assert flip_direction in ['horizontal', 'vertical']
+            flip = 1 if flip_direction == 'horizontal' else 2
+        prob, label, _ = K.softmax_argmax(seg_logit.contiguous(), want_prob=True, flip=flip)
+        return (prob, label) if return_labels else prob
+
+    def simple_test(self, img, img_meta, rescale=True):
+        """encoder_decoder.py:1205-1223 -> list of [H, W] integer label maps (numpy), one per image"""
+        _, label = self.inference(img, img_meta, rescale, return_labels=True)
+        return list(label.cpu().numpy().astype(np.int64))
+
+    def aug_test(self, imgs, img_metas, rescale=True):
+        """encoder_decoder.py:1249-1267: mean of the augmentations' probabilities, then arg-max"""
+        assert rescale
+        seg_logit = self.inference(imgs[0], img_metas[0], rescale)
+        for i in range(1, len(imgs)):
+            seg_logit += self.inference(imgs[i], img_metas[i], rescale)
+        seg_logit /= len(imgs)
+        _, label, _ = K.softmax_argmax(seg_logit.contiguous(), want_prob=False, flip=0, raw=True)    # arg-max of the mean probabilities
+        return list(label.cpu().numpy().astype(np.int64))
 
     # ------------------------------------------------------------------ EMA
     def update_ema_variables(self, model=None, ema_model=None, momentum=None, dropout=0.0, attn_frozen=False):

@@ -15,7 +15,7 @@ __all__ = ['gemm', 'wgrad_grouped', 'transpose_many', 'cast', 'cast_back', 'im2c
            'layernorm_bwd', 'add_f32', 'attention_fwd', 'attention_bwd', 'bn_stats', 'bn_finalize',
            'bn_relu_up_fwd', 'bn_relu_up_bwd', 'bn_bwd_apply', 'bn_param_grads', 'upce_fwd', 'upce_bwd',
            'up_pseudo_label', 'up_logits_nchw', 'ce_fwd', 'ce_bwd', 'ema', 'sgd_momentum', 'ncr_fwd', 'ncr_bwd', 'mix_images',
-           'cutmix_labels', 'gather_rows']
+           'cutmix_labels', 'gather_rows', 'resize_bilinear', 'softmax_argmax', 'confusion_counts']
 
 
 def _need(t, n, what):
@@ -537,6 +537,46 @@ def gather_rows(src, out, row_map, rows, C):
     if C % 4:
         raise S4FError('gather_rows: C must be a multiple of 4')
     call('s4f_gather_rows', p(src), p(out), p(row_map), rows, C, stream())
+
+
+def resize_bilinear(x, size, align_corners=False, window=None):
+    """mmseg.ops.resize(x, size, mode='bilinear', align_corners) on fp32 NCHW; window = (h, w): read only x[..., :h, :w]"""
+    if x.dim() != 4:
+        raise S4FError('resize_bilinear: NCHW expected')
+    _chk_f32(x, 'resize x')
+    if not x.is_contiguous():
+        raise S4FError('resize_bilinear: contiguous input expected (pass a window instead of slicing)')
+    B, C, H, W = x.shape
+    ih, iw = (H, W) if window is None else (int(window[0]), int(window[1]))
+    if not (0 < ih <= H and 0 < iw <= W):
+        raise S4FError(f'resize_bilinear: window {(ih, iw)} outside the {H}x{W} plane')
+    oh, ow = int(size[0]), int(size[1])
+    out = torch.empty(B, C, oh, ow, device=x.device, dtype=torch.float32)
+    call('s4f_resize_bilinear_nchw', p(x), p(out), B * C, ih, iw, H * W, W, oh, ow, 1 if align_corners else 0, stream())
+    return out
+
+
+def softmax_argmax(logits, want_prob=True, flip=0, raw=False):
+    """-> (prob fp32 NCHW | None, label uint8 [B, H, W], pmax fp32 [B, H, W]) of fp32 NCHW logits; flip 0 | 1 (h) | 2 (v);
+    raw=True: the input already holds probabilities, arg-max only"""
+    _chk_f32(logits, 'softmax logits')
+    if logits.dim() != 4 or not logits.is_contiguous():
+        raise S4FError('softmax_argmax: contiguous NCHW expected')
+    B, C, H, W = logits.shape
+    prob = torch.empty_like(logits) if want_prob else None
+    label = torch.empty(B, H, W, device=logits.device, dtype=torch.uint8)
+    pmax = torch.empty(B, H, W, device=logits.device, dtype=torch.float32)
+    call('s4f_softmax_argmax_nchw', p(logits), p(prob), p(label), p(pmax), B, C, H, W, int(flip), 1 if raw else 0, stream())
+    return prob, label, pmax
+
+
+def confusion_counts(pred, label, num_classes, ignore_index, counts):
+    """counts int64 [3, num_classes] += (intersect, prediction, label) pixel counts over label != ignore_index"""
+    n = label.numel()
+    _chk_u8(pred, n, 'confusion pred'); _chk_u8(label, n, 'confusion label')
+    if counts.dtype != torch.int64 or counts.numel() < 3 * num_classes or not counts.is_cuda:
+        raise S4FError('confusion_counts: counts must be a device int64 tensor of 3 * num_classes')
+    call('s4f_confusion_counts', p(pred), p(label), n, num_classes, ignore_index, p(counts), stream())
 
 
 def ce_fwd(logits, labels, class_weight, loss_elem, N, C, spatial, ignore_index):

@@ -183,3 +183,22 @@ def fragile_pixels(z, logit_tol, th=0.95):
     out = np.zeros(int(np.prod(shape)), dtype=bool)
     out[idx] = (margin < logit_tol) | (np.abs(pmax - th) < 0.5 * logit_tol + 1e-7)
     return out.reshape(shape)
+
+
+METRIC_CASES = {'voc21': (21, False), 'city19': (19, False), 'ade_rz': (20, True)}     # name: (num_classes, reduce_zero_label)
+
+
+def metric_maps(name, n=3, size=(97, 131)):
+    """seeded prediction / label maps for the metric fixtures: labels with an ignore band (255), predictions that agree on ~60 %
+    of the pixels; 'ade_rz' labels start at 0 = "nothing" (reduce_zero_label)"""
+    ncls, rz = METRIC_CASES[name]
+    g = np.random.RandomState(hash(name) % 1000 + 7 if False else {'voc21': 11, 'city19': 12, 'ade_rz': 13}[name])
+    preds, labels = [], []
+    for i in range(n):
+        hi = ncls + 1 if rz else ncls
+        lab = g.randint(0, hi, size=size).astype(np.uint8)
+        lab[: 5 + i] = 255
+        pred = np.where(g.rand(*size) < 0.6, (lab.astype(np.int64) - (1 if rz else 0)) % ncls, g.randint(0, ncls, size=size)).astype(np.int64)
+        preds.append(pred)
+        labels.append(lab)
+    return preds, labels
