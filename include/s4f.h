@@ -242,6 +242,18 @@ int s4f_softmax_argmax_nchw(const float* logits, float* prob, uint8_t* label, fl
 int s4f_confusion_counts(const uint8_t* pred, const uint8_t* label, int64_t n, int num_classes, int ignore_index,
                          unsigned long long* counts, s4f_stream stream);
 
+/* ---- device half of the training input pipeline --------------------------------------------------------
+ * One view of one sample after decode + Resize: RandomCrop window -> RandomFlip -> PhotoMetricDistortion -> Normalize ->
+ * Pad -> CHW fp32 (configs/setr/..._MT.py:41-118; mmseg/datasets/pipelines/transforms.py:429-611, 802-875, 1165-1285).
+ * img uint8 [H, W, 3] BGR and seg uint8 [H, W] (or NULL) are DEVICE buffers; crop = HOST int[4] (y, x, h, w), clipped to the
+ * image, h <= OH, w <= OW; flip 0 | 1 horizontal | 2 vertical; photo = HOST float[9]:
+ * (brightness on, delta, contrast on, alpha, contrast before the HSV stages (mode 1), saturation on, alpha, hue on, delta);
+ * mean / std = HOST float[3] in the OUTPUT channel order; out_img fp32 [3, OH, OW] padded with pad_val, out_seg uint8
+ * [OH, OW] padded with seg_pad_val (NULL allowed).  The decisions are drawn on the host (s4former_amd/pipeline.py). */
+int s4f_input_view(const uint8_t* img, const uint8_t* seg, float* out_img, uint8_t* out_seg, int H, int W, int OH, int OW,
+                   const int* crop, int flip, const float* photo, const float* mean, const float* std, int to_rgb, float pad_val,
+                   int seg_pad_val, s4f_stream stream);
+
 /* Stand-alone CrossEntropyLoss on NCHW / [N,C] fp32 logits (cross_entropy_loss.py:12-63): per-element loss
  * (0 where ignored), optional class weights; spatial = H*W (1 for [N,C]). */
 int s4f_ce_fwd(const float* logits, const int64_t* labels, const float* class_weight, float* loss_elem, int64_t N,

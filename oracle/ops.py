@@ -286,3 +286,91 @@ def mean_iou(results, gt_seg_maps, num_classes, ignore_index, reduce_zero_label=
             t += a
     ai, au, ap, al = tot
     return dict(aAcc=(ai.sum() / al.sum()).numpy(), IoU=(ai / au).numpy(), Acc=(ai / al).numpy()), tot
+
+
+# ---------------------------------------------------------------------------------------------- input pipeline (§8f-3)
+# numpy restatement of the per-view pipeline after Resize (mmseg/datasets/pipelines/transforms.py:429-611, 802-875, 1165-1285).
+# cv2 is NOT in the build image: bgr2hsv / hsv2bgr restate OpenCV's published 8-bit algorithm (RGB2HSV_b with the 12-bit
+# division tables, HSV2RGB_b through the float sector formula) - PARITY UNPINNED for these two functions; everything else is
+# numpy arithmetic exactly as the reference writes it.
+def _bgr2hsv_u8(img):
+    import numpy as np
+    b, g, r = (img[..., i].astype(np.int64) for i in range(3))
+    v = np.maximum(b, np.maximum(g, r))
+    vmin = np.minimum(b, np.minimum(g, r))
+    diff = v - vmin
+    with np.errstate(divide='ignore'):
+        sdiv = np.where(v > 0, np.rint((255 << 12) / (1.0 * np.maximum(v, 1))), 0).astype(np.int64)
+        hdiv = np.where(diff > 0, np.rint((180 << 12) / (6.0 * np.maximum(diff, 1))), 0).astype(np.int64)
+    s = (diff * sdiv + (1 << 11)) >> 12
+    h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * hdiv + (1 << 11)) >> 12
+    h = np.where(h < 0, h + 180, h)
+    return np.stack([h, s, v], -1).astype(np.uint8)
+
+
+def _hsv2bgr_u8(hsv):
+    import numpy as np
+    f32 = np.float32
+    h = hsv[..., 0].astype(f32) * f32(6.0 / 180.0)
+    s = hsv[..., 1].astype(f32) * f32(1.0 / 255.0)
+    v = hsv[..., 2].astype(f32) * f32(1.0 / 255.0)
+    sector = np.floor(h).astype(np.int64)
+    fr = (h - sector.astype(f32)).astype(f32)
+    sector = np.where((sector < 0) | (sector >= 6), 0, sector)
+    t0, t1 = v, (v * (f32(1) - s)).astype(f32)
+    t2 = (v * (f32(1) - (s * fr).astype(f32))).astype(f32)
+    t3 = (v * (f32(1) - (s * (f32(1) - fr)).astype(f32))).astype(f32)
+    tab = np.stack([t0, t1, t2, t3], -1)
+    sel = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])[sector]       # (b, g, r) table index
+    bgr = np.take_along_axis(tab, sel, -1)
+    bgr = np.where((s == 0)[..., None], v[..., None], bgr)
+    return np.clip(np.rint((bgr * f32(255)).astype(f32)), 0, 255).astype(np.uint8)
+
+
+def photometric(img, p):
+    """PhotoMetricDistortion with the drawn parameters p = (bright on, delta, contrast on, alpha, contrast first, sat on, alpha,
+    hue on, delta) on a uint8 BGR image (transforms.py:1197-1268)"""
+    import numpy as np
+
+    def convert(x, alpha=1, beta=0):
+        return np.clip(x.astype(np.float32) * np.float32(alpha) + np.float32(beta), 0, 255).astype(np.uint8)
+    if p[0]:
+        img = convert(img, beta=p[1])
+    if p[2] and p[4]:
+        img = convert(img, alpha=p[3])
+    if p[5]:
+        hsv = _bgr2hsv_u8(img)
+        hsv[..., 1] = convert(hsv[..., 1], alpha=p[6])
+        img = _hsv2bgr_u8(hsv)
+    if p[7]:
+        hsv = _bgr2hsv_u8(img)
+        hsv[..., 0] = (hsv[..., 0].astype(int) + int(p[8])) % 180
+        img = _hsv2bgr_u8(hsv)
+    if p[2] and not p[4]:
+        img = convert(img, alpha=p[3])
+    return img
+
+
+def input_view(img, seg, bbox, flip, p, crop_size, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True):
+    """RandomCrop.crop -> RandomFlip (horizontal) -> PhotoMetricDistortion -> Normalize -> Pad -> CHW
+    (transforms.py:826-832, 450-481, 1241-1268, 589-611, 541-569).  -> (img fp32 [3, ch, cw], seg uint8 [ch, cw])"""
+    import numpy as np
+    y1, y2, x1, x2 = bbox
+    img = img[y1:y2, x1:x2]
+    seg = seg[y1:y2, x1:x2] if seg is not None else None
+    if flip:
+        img = img[:, ::-1]
+        seg = seg[:, ::-1] if seg is not None else None
+    img = photometric(np.ascontiguousarray(img), p).astype(np.float32)
+    if to_rgb:
+        img = img[..., ::-1]
+    stdinv = (1.0 / np.asarray(std, dtype=np.float64)).astype(np.float32)
+    img = (img - np.asarray(mean, dtype=np.float32)) * stdinv
+    out = np.zeros((crop_size[0], crop_size[1], 3), dtype=np.float32)
+    out[:img.shape[0], :img.shape[1]] = img
+    so = None
+    if seg is not None:
+        so = np.full(crop_size, 255, dtype=np.uint8)
+        so[:seg.shape[0], :seg.shape[1]] = seg
+    return np.ascontiguousarray(out.transpose(2, 0, 1)), so

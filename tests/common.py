@@ -202,3 +202,14 @@ def metric_maps(name, n=3, size=(97, 131)):
         preds.append(pred)
         labels.append(lab)
     return preds, labels
+
+
+SAMPLER_CASES = {
+    # VOC 1/16 classic split of the SETR configs: 662 labelled + 9920 unlabelled, 4 + 4 per GPU (configs/setr/*:31-33)
+    'voc16_8gpu': dict(cumulative_sizes=[662, 10582], sample_ratio=[1, 1], samples_per_gpu=8, num_replicas=8, max_iter_size=40,
+                       epochs=[0, 3]),
+    'small_1gpu': dict(cumulative_sizes=[10, 37], sample_ratio=[1, 1], samples_per_gpu=4, num_replicas=1, max_iter_size=25,
+                       epochs=[0, 1]),
+    'ratio_1_3': dict(cumulative_sizes=[20, 100], sample_ratio=[1, 3], samples_per_gpu=8, num_replicas=2, max_iter_size=12,
+                      epochs=[5]),
+}
