@@ -129,10 +129,13 @@ template <typename T, int NT> struct TilePF {
 };
 
 // ------------------------------------------------------------------------------------------ forward
-// block = NW waves x 32 queries; K/V tiles of 64 keys double-buffered in LDS, the next tile is fetched into
-// registers while the current one is consumed (one barrier per tile).
-template <typename T, int NW, bool HAS_BIAS>
-__global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void attn_fwd_kernel(const AttnArgs a) {
+// block = NW waves x 16 QT queries; K/V tiles of 64 keys double-buffered in LDS, the next tile is fetched into
+// registers while the current one is consumed (one barrier per tile).  QT = query sub-tiles (16 queries) per wave: every K
+// fragment (ds_read_b128) and V fragment (two ds_read_b64_tr) read from LDS feeds QT MFMAs.  At QT = 2 the four SIMDs of a
+// CU read 128 B/clk of fragments at full MFMA rate - exactly the LDS bandwidth, which is what held the kernel at 25 % MFMA
+// busy; QT = 4 halves the LDS bytes per MFMA (64 accumulator registers for S^T, 64 for O, two waves per SIMD).
+template <typename T, int NW, bool HAS_BIAS, int QT>
+__global__ __launch_bounds__(64 * NW, (QT == 4) ? 2 : ((NW == 8 && sizeof(T) == 2) ? 3 : ((NW == 4 && sizeof(T) == 2) ? 3 : 1))) void attn_fwd_kernel(const AttnArgs a) {
   using C = ACfg<T>;
   constexpr int NT = 64 * NW;
   constexpr int BUF = 2 * C::TILE_BYTES + 64 * 4;
@@ -145,21 +148,23 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
   const T* qb = reinterpret_cast<const T*>(a.qkv) + (long)b * N * ld + h * 64;
   const T* kb = qb + H * 64;
   const T* vb = qb + 2 * H * 64;
-  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  const int q0 = blockIdx.x * (16 * QT) * NW + wave * (16 * QT);
 
-  Frag<T> fq[2][2];
-  float flagq[2];
+  Frag<T> fq[QT][2];
+  float flagq[QT];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int q = q0 + qt * 16 + li;
 #pragma unroll
     for (int s = 0; s < 2; ++s) gload_frag<T>(fq[qt][s], qb + (long)q * ld + s * 32 + 8 * g, q < N);
     flagq[qt] = (HAS_BIAS && a.row_flag && q < N) ? a.row_flag[(long)b * N + q] : 1.f;
   }
-  float m[2] = {-INFINITY, -INFINITY}, lsum[2] = {0.f, 0.f};
-  f32x4 o[2][4];
+  float m[QT], lsum[QT];
+  f32x4 o[QT][4];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt)
+  for (int qt = 0; qt < QT; ++qt) { m[qt] = -INFINITY; lsum[qt] = 0.f; }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
     const bool more = t + 1 < ntile;
     if (more) fetch(t + 1);
     if (active) {
-    f32x4 st[4][2];
+    f32x4 st[4][QT];
     const f32x4 zero4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -205,7 +210,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
         Frag<T> fk;
         tile_rowfrag<T>(fk, Ks, ks * 16 + li, s);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) st[ks][qt] = mma16(fk, fq[qt][s], s == 0 ? zero4 : st[ks][qt]);
+        for (int qt = 0; qt < QT; ++qt) st[ks][qt] = mma16(fk, fq[qt][s], s == 0 ? zero4 : st[ks][qt]);
       }
     // Scores stay RAW (q.k) in the no-bias case: p = exp2(fma(raw, c, -m c)) with c = log2(e)/8 and m the running
     // raw maximum (c > 0, so max commutes).  With the PASA bias they are moved to log2 units first.
@@ -216,7 +221,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
         const f32x4 uu = *reinterpret_cast<const f32x4*>(us + ks * 16 + 4 * g);
         const f32x4 k4 = f32x4{kScale2, kScale2, kScale2, kScale2};
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) st[ks][qt] = __builtin_elementwise_fma(st[ks][qt], k4, uu * flagq[qt]);   // packed fp32
+        for (int qt = 0; qt < QT; ++qt) st[ks][qt] = __builtin_elementwise_fma(st[ks][qt], k4, uu * flagq[qt]);   // packed fp32
       }
     }
     if (ragged) {
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
         for (int r = 0; r < 4; ++r)
           if ((k0 + ks * 16 + 4 * g + r) >= N) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) st[ks][qt][r] = -INFINITY;
+            for (int qt = 0; qt < QT; ++qt) st[ks][qt][r] = -INFINITY;
           }
     }
     constexpr float kc = HAS_BIAS ? 1.f : kScale2;      // units of m / st relative to log2 units
@@ -235,10 +240,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
     // the wave sees such a jump (wave vote) are the maxima reduced across the four lanes of a query (two dependent
     // cross-lane shuffles per query tile) - after the first tiles that is rare.  fp32 parity mode: exact running maximum.
     constexpr float kDefer = sizeof(T) == 2 ? 6.0f : 0.0f;
-    float alpha[2] = {1.f, 1.f};
-    float mxl[2];
+    float alpha[QT];
+    float mxl[QT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) alpha[qt] = 1.f;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
       // v_max3_f32 written out: fmaxf() makes the compiler canonicalise every MFMA result first (one extra v_max each)
       float mx = max3f(st[0][qt][0], st[0][qt][1], st[0][qt][2]);
       mx = max3f(mx, st[0][qt][3], st[1][qt][0]);
@@ -250,10 +257,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
       }
       mxl[qt] = mx;
     }
-    const bool jump = !((mxl[0] - m[0]) * kc <= kDefer) || !((mxl[1] - m[1]) * kc <= kDefer);   // (m = -inf: true)
+    bool jump = false;                                                  // (m = -inf: true)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) jump = jump || !((mxl[qt] - m[qt]) * kc <= kDefer);
     if (__any(jump)) {
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
+      for (int qt = 0; qt < QT; ++qt) {
         float mx = mxl[qt];
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -266,7 +275,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
     // the row sums stay lane-partial (each of a query's four lanes sums its own 16 keys of every tile; same alpha in all
     // four): they are reduced across lanes once, after the last tile
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
       const float mc = -m[qt] * kc;
       const f32x4 mc4 = f32x4{mc, mc, mc, mc}, kc4 = f32x4{kc, kc, kc, kc};
       f32x4 ps4 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -280,9 +289,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
       lsum[qt] = lsum[qt] * alpha[qt] + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
     }
     // rescale O only when some query of this wave moved its maximum (wave-uniform branch)
-    if (!__all(alpha[0] == 1.f && alpha[1] == 1.f)) {
+    bool same = true;
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt) same = same && alpha[qt] == 1.f;
+    if (!__all(same)) {
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float al = __shfl(alpha[qt], 4 * g + r, 64);
@@ -292,15 +304,15 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
     }
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
-      Frag<T> pa[2];
+      Frag<T> pa[QT];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) acc_to_frag<T>(pa[qt], st[2 * ms][qt], st[2 * ms + 1][qt]);
+      for (int qt = 0; qt < QT; ++qt) acc_to_frag<T>(pa[qt], st[2 * ms][qt], st[2 * ms + 1][qt]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         Frag<T> fv;
         lds_read_tr(fv, Vs, C::STRIDE, ms * 32, dt * 16);
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mma16(pa[qt], fv, o[qt][dt]);
+        for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mma16(pa[qt], fv, o[qt][dt]);
       }
     }
     }
@@ -310,7 +322,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
 
   T* cb = reinterpret_cast<T*>(a.ctx) + (long)b * N * (H * 64) + h * 64;
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     lsum[qt] += __shfl_xor(lsum[qt], 16, 64);        // lane-partial row sums -> row sums
     lsum[qt] += __shfl_xor(lsum[qt], 32, 64);
     const float il = 1.f / lsum[qt];
@@ -329,6 +341,225 @@ __global__ __launch_bounds__(64 * NW, (NW == 4 && sizeof(T) == 2) ? 3 : 1) void 
 }
 
 // ------------------------------------------------------------------------------------------ dQ
+// ------------------------------------------------------------------------------------------ forward, bf16, VALU diet
+// The forward above is bound by the SIMD's vector ISSUE port, not by the MFMA pipe or the LDS (MI355X_MICROARCH 'vector-
+// instruction ISSUE cost': an MFMA 16x16x32 holds the port 8 cycles, v_exp_f32 8, every other VALU op 4-5, and packed fp32
+// ops cost MORE than their two scalar halves beside MFMAs): per 64-key tile a wave issued 32 MFMAs (256 cycles) + ~770
+// cycles of VALU for 32 score registers, against 512 cycles of MFMA work.  This variant removes VALU work per score:
+//  * Q is scaled by log2(e) / 8 once when its fragments are loaded (one more bf16 rounding of q), so the MFMA output is in
+//    log2 units already;
+//  * the accumulators of S^T start at -m (running maximum of the lane's query) [+ w u_key flag_query with the PASA bias]:
+//    S' = S - m comes out of the MFMA chain and p = exp2(S') needs no subtraction (guide: "row constants as the initial
+//    accumulator"); m moves only when a tile's maximum exceeds it by 2^6 (and on the first tile), then that tile pays one
+//    subtraction per score;
+//  * the row sums are one more MFMA per P fragment against an all-ones B operand (4 MFMAs per tile instead of 32 v_add);
+//    they land on the same lanes / registers as the rows of O, so the epilogue needs no shuffle for the normalisation.
+// Measured and rejected for the ragged last block of every (image, head) pair (N = 1025 = 8 x 128 + 1: 11 % more blocks for one
+// query row each): the row as a fifth wave of the last block (320-thread blocks ran 55 % slower) and a 1-D grid that
+// dispatches the ragged blocks last (no change: the scheduler back-fills, there are no "rounds" to save).
+template <int NW, bool HAS_BIAS>
+__global__ __launch_bounds__(64 * NW, 3) void attn_fwd2_kernel(const AttnArgs a) {
+  using T = bf16_t;
+  using C = ACfg<T>;
+  constexpr int NT = 64 * NW;
+  constexpr int BUF = 2 * C::TILE_BYTES + 64 * 4;
+  __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+  const int N = a.N, H = a.H;
+  const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x;
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
+  const long ld = 3L * H * 64;
+  const T* qb = reinterpret_cast<const T*>(a.qkv) + (long)b * N * ld + h * 64;
+  const T* kb = qb + H * 64;
+  const T* vb = qb + 2 * H * 64;
+  const int q0 = qblk * 32 * NW + wave * 32;
+
+  Frag<T> fq[2][2];
+  float flagq[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int q = q0 + qt * 16 + li;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      gload_frag<T>(fq[qt][s], qb + (long)q * ld + s * 32 + 8 * g, q < N);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) fq[qt][s].v[j] = (bf16_t)((float)fq[qt][s].v[j] * kScale2);
+    }
+    flagq[qt] = (HAS_BIAS && a.row_flag && q < N) ? a.row_flag[(long)b * N + q] : 1.f;
+  }
+  Frag<T> ones;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ones.v[j] = (bf16_t)1.0f;
+  float m[2] = {0.f, 0.f};                      // log2 units; set from the first tile
+  f32x4 o[2][4], osum[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    osum[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[qt][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  TilePF<T, NT> pk, pv;
+  pk.init(kb, ld);
+  pv.init(vb, ld);
+  float pu = 0.f;
+  const int ntile = (N + 63) / 64;
+  auto fetch = [&](int t) {
+    pk.load(t * 64, N);
+    pv.load(t * 64, N);
+    if (HAS_BIAS && threadIdx.x < 64) {
+      const int key = t * 64 + threadIdx.x;
+      pu = key < N ? a.bias_w * kLog2e * a.bias_u[(long)b * N + key] : 0.f;
+    }
+  };
+  auto commit = [&](int buf) {
+    char* base = smem + buf * BUF;
+    pk.store(base);
+    pv.store(base + C::TILE_BYTES);
+    if (HAS_BIAS && threadIdx.x < 64) reinterpret_cast<float*>(base + 2 * C::TILE_BYTES)[threadIdx.x] = pu;
+  };
+  fetch(0);
+  commit(0);
+  __syncthreads();
+  const bool active = q0 < N;
+  constexpr float kDefer = 6.0f;
+
+  for (int t = 0; t < ntile; ++t) {
+    const int k0 = t * 64;
+    const char* Ks = smem + (t & 1) * BUF;
+    const char* Vs = Ks + C::TILE_BYTES;
+    const float* us = reinterpret_cast<const float*>(Ks + 2 * C::TILE_BYTES);
+    const bool more = t + 1 < ntile;
+    if (more) fetch(t + 1);
+    if (active) {
+      f32x4 st[4][2];
+      f32x4 nm4[2];                       // the C operand of the first k-step: a splat of -m, never copied into st
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) nm4[qt] = f32x4{-m[qt], -m[qt], -m[qt], -m[qt]};
+      if (HAS_BIAS) {                     // with the PASA bias the start value differs per key: w u_key flag_query - m
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const f32x4 uu = *reinterpret_cast<const f32x4*>(us + ks * 16 + 4 * g);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[ks][qt][r] = __builtin_fmaf(uu[r], flagq[qt], -m[qt]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          Frag<T> fk;
+          tile_rowfrag<T>(fk, Ks, ks * 16 + li, s);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            if (s == 0 && !HAS_BIAS) st[ks][qt] = mma16(fk, fq[qt][0], nm4[qt]);
+            else st[ks][qt] = mma16(fk, fq[qt][s], st[ks][qt]);
+          }
+        }
+      if (k0 + 64 > N) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if ((k0 + ks * 16 + 4 * g + r) >= N) {
+#pragma unroll
+              for (int qt = 0; qt < 2; ++qt) st[ks][qt][r] = -INFINITY;
+            }
+      }
+      // lane-local maxima of S' = S - m; the running maximum moves on the first tile and when a tile exceeds it by 2^kDefer
+      float mxl[2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        float mx = max3f(st[0][qt][0], st[0][qt][1], st[0][qt][2]);
+        mx = max3f(mx, st[0][qt][3], st[1][qt][0]);
+#pragma unroll
+        for (int ks = 1; ks < 4; ++ks) {
+          mx = max3f(mx, st[ks][qt][1], st[ks][qt][2]);
+          if (ks < 3) mx = max3f(mx, st[ks][qt][3], st[ks + 1][qt][0]);
+          else mx = fmaxf(mx, st[ks][qt][3]);
+        }
+        mxl[qt] = mx;
+      }
+      const bool jump = (t == 0) || !(mxl[0] <= kDefer) || !(mxl[1] <= kDefer);
+      if (__any(jump)) {
+        float alpha[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          float mx = mxl[qt];
+          mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+          mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                // finite: every tile has >= 1 valid key
+          const float d = (t == 0 || mx > kDefer) ? mx : 0.f;    // shift of this query's maximum
+          alpha[qt] = (t == 0) ? 1.f : __builtin_amdgcn_exp2f(-d);
+          m[qt] += d;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[ks][qt][r] -= d;
+        }
+        if (t > 0) {
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float al = __shfl(alpha[qt], 4 * g + r, 64);
+              osum[qt][r] *= al;
+#pragma unroll
+              for (int dt = 0; dt < 4; ++dt) o[qt][dt][r] *= al;
+            }
+        }
+      }
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) st[ks][qt][r] = __builtin_amdgcn_exp2f(st[ks][qt][r]);
+#pragma unroll
+      for (int ms = 0; ms < 2; ++ms) {
+        Frag<T> pa[2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          acc_to_frag<T>(pa[qt], st[2 * ms][qt], st[2 * ms + 1][qt]);
+          osum[qt] = mma16(pa[qt], ones, osum[qt]);              // row sums of the bf16 P that multiplies V
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          Frag<T> fv;                     // (requesting the tile's eight V fragments ahead of the softmax was measured: no gain,
+          lds_read_tr(fv, Vs, C::STRIDE, ms * 32, dt * 16);      //  +84 VGPRs - the LDS latency is not what the wave waits for)
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mma16(pa[qt], fv, o[qt][dt]);
+        }
+      }
+    }
+    if (more) commit((t + 1) & 1);
+    __syncthreads();
+  }
+
+  T* cb = reinterpret_cast<T*>(a.ctx) + (long)b * N * (H * 64) + h * 64;
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float ilr = 1.f / osum[qt][r];                       // row 4 g + r: every column of the ones product holds its sum
+      const int q = q0 + qt * 16 + 4 * g + r;
+      if (q < N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) cb[(long)q * (H * 64) + dt * 16 + li] = from_f32<T>(o[qt][dt][r] * ilr);
+      }
+    }
+    // log-sum-exp of query li: its row sum sits in register (li & 3) of the lanes with g == li >> 2
+    float mine = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = __shfl(osum[qt][r], (li >> 2) * 16, 64);
+      mine = ((li & 3) == r) ? v : mine;
+    }
+    const int q = q0 + qt * 16 + li;
+    if (g == 0 && q < N) a.lse[((long)b * H + h) * N + q] = (m[qt] + __log2f(mine)) * kLn2;
+  }
+}
+
 template <typename T, int NW, bool HAS_BIAS>
 __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
   using C = ACfg<T>;
@@ -656,11 +887,11 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
     }
 }
 
-template <typename T, int NW>
+template <typename T, int NW, int QT = 2>
 int fwd_launch(const AttnArgs& a, hipStream_t st) {
-  dim3 grid(ceil_div(a.N, 32 * NW), a.H, a.B);
-  if (a.bias_u) hipLaunchKernelGGL((attn_fwd_kernel<T, NW, true>), grid, dim3(64 * NW), 0, st, a);
-  else hipLaunchKernelGGL((attn_fwd_kernel<T, NW, false>), grid, dim3(64 * NW), 0, st, a);
+  dim3 grid(ceil_div(a.N, 16 * QT * NW), a.H, a.B);
+  if (a.bias_u) hipLaunchKernelGGL((attn_fwd_kernel<T, NW, true, QT>), grid, dim3(64 * NW), 0, st, a);
+  else hipLaunchKernelGGL((attn_fwd_kernel<T, NW, false, QT>), grid, dim3(64 * NW), 0, st, a);
   return 0;
 }
 template <typename T, int NW>
@@ -676,12 +907,22 @@ int bwd_launch(const AttnArgs& a, hipStream_t st) {
   return 0;
 }
 
+// query sub-tiles per wave of the bf16 forward: S4F_ATTN_QT (2 | 4)
+static int attn_qt() {
+  static int v = [] {
+    const char* e = getenv("S4F_ATTN_QT");
+    const int n = e ? atoi(e) : 2;
+    return n == 4 ? 4 : 2;
+  }();
+  return v;
+}
+
 // waves per block: the environment variable S4F_ATTN_NW (2 | 3 | 4) overrides the default for experiments
 static int attn_nw() {
   static int v = [] {
     const char* e = getenv("S4F_ATTN_NW");
     const int n = e ? atoi(e) : 4;
-    return (n == 2 || n == 3 || n == 4) ? n : 4;
+    return (n == 2 || n == 3 || n == 4 || n == 8) ? n : 4;
   }();
   return v;
 }
@@ -700,7 +941,14 @@ S4F_API int s4f_attention_fwd(const void* qkv, void* ctx, float* lse, const floa
   const int nw = attn_nw();
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S4F_BF16) {
-    if (nw == 2) fwd_launch<bf16_t, 2>(a, st); else if (nw == 3) fwd_launch<bf16_t, 3>(a, st); else fwd_launch<bf16_t, 4>(a, st);
+    static const bool diet = [] { const char* e = getenv("S4F_ATTN_FWD2"); return !e || atoi(e) != 0; }();
+    if (diet) {
+      dim3 grid(ceil_div(a.N, 128), a.H, a.B);
+      if (a.bias_u) hipLaunchKernelGGL((attn_fwd2_kernel<4, true>), grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((attn_fwd2_kernel<4, false>), grid, dim3(256), 0, st, a);
+    } else if (attn_qt() == 4) {
+      if (nw == 2) fwd_launch<bf16_t, 2, 4>(a, st); else fwd_launch<bf16_t, 4, 4>(a, st);
+    } else if (nw == 2) fwd_launch<bf16_t, 2>(a, st); else if (nw == 3) fwd_launch<bf16_t, 3>(a, st); else if (nw == 8) fwd_launch<bf16_t, 8>(a, st); else fwd_launch<bf16_t, 4>(a, st);
   } else {
     fwd_launch<float, 2>(a, st);
   }
@@ -720,7 +968,7 @@ S4F_API int s4f_attention_bwd(const void* qkv, const void* ctx, const void* dctx
   const int nw = attn_nw();
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S4F_BF16) {
-    if (nw == 2) bwd_launch<bf16_t, 2>(a, st); else if (nw == 3) bwd_launch<bf16_t, 3>(a, st); else bwd_launch<bf16_t, 4>(a, st);
+    if (nw == 2) bwd_launch<bf16_t, 2>(a, st); else if (nw == 3) bwd_launch<bf16_t, 3>(a, st); else if (nw == 8) bwd_launch<bf16_t, 8>(a, st); else bwd_launch<bf16_t, 4>(a, st);
   } else {
     bwd_launch<float, 2>(a, st);
   }
