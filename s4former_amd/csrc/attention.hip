@@ -563,6 +563,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_fwd2_kernel(const AttnArgs a)
 template <typename T, int NW, bool HAS_BIAS>
 __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
   using C = ACfg<T>;
+  constexpr bool PRESCALE = sizeof(T) == 2;
   constexpr int NT = 64 * NW;
   constexpr int BUF = 2 * C::TILE_BYTES + 64 * 4;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
@@ -595,6 +596,12 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
       gload_frag<T>(fo, ob + (long)q * ldc + s * 32 + 8 * g, v);
 #pragma unroll
       for (int j = 0; j < 8; ++j) dsum += to_f32<T>(fdo[qt][s].v[j]) * to_f32<T>(fo.v[j]);
+      // bf16: q enters the score MFMA already scaled to log2 units, with the very rounding the forward kernel applies
+      // (attn_fwd2_kernel): the recomputed P equals the forward's, and the per-score multiply is gone
+      if constexpr (PRESCALE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) frag_set<T>(fq[qt][s], j, to_f32<T>(fq[qt][s].v[j]) * kScale2);
+      }
     }
     dsum += __shfl_xor(dsum, 16, 64);               // the four lanes of a query hold 16 of its 64 head dims each
     dsum += __shfl_xor(dsum, 32, 64);
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
   f32x4 sinit[2], dinit[2];
 #pragma unroll
   for (int qt = 0; qt < 2; ++qt) {
-    const float s0 = -lse2[qt] * (1.f / kScale2), d0 = -delq[qt];
+    const float s0 = PRESCALE ? -lse2[qt] : -lse2[qt] * (1.f / kScale2), d0 = -delq[qt];
     sinit[qt] = f32x4{s0, s0, s0, s0};
     dinit[qt] = f32x4{d0, d0, d0, d0};
   }
@@ -665,7 +672,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
           dp[ks][qt] = mma16(fv, fdo[qt][s], s == 0 ? dinit[qt] : dp[ks][qt]);
         }
       }
-    const bool ragged = (k0 + 64 > N);
+    // (keys beyond N need no masking here: their K rows are zero in the LDS image, so whatever dS holds for them adds
+    //  nothing to dQ = dS K; p and dP' stay finite - S' = -lse, dP' = -delta)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       f32x4 uu = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -674,20 +682,12 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
       for (int r = 0; r < 4; ++r) {
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          const float e = HAS_BIAS ? fmaf(st[ks][qt][r], kScale2, uu[r] * flagq[qt]) : st[ks][qt][r] * kScale2;
+          float e;
+          if constexpr (PRESCALE) e = HAS_BIAS ? fmaf(uu[r], flagq[qt], st[ks][qt][r]) : st[ks][qt][r];
+          else e = HAS_BIAS ? fmaf(st[ks][qt][r], kScale2, uu[r] * flagq[qt]) : st[ks][qt][r] * kScale2;
           st[ks][qt][r] = fexp2<T>(e) * dp[ks][qt][r];
         }
       }
-    }
-    if (ragged) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if ((k0 + ks * 16 + 4 * g + r) >= N) {
-#pragma unroll
-            for (int qt = 0; qt < 2; ++qt) st[ks][qt][r] = 0.f;
-          }
     }
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
@@ -796,7 +796,8 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
     const bool more = t + 1 < ntile;
     if (more) fetch(t + 1);
     if (active) {
-    const bool ragged = (q0 + 64 > N);
+    // (query rows beyond N need no masking: their Q and dO rows are zero in the LDS images, so they add nothing to
+    //  dV = P^T dO and dK = dS^T Q; p = exp2(0 - 0) = 1 and dS = -delta = 0 stay finite)
 
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
@@ -838,14 +839,6 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
             sc[qs][kt][r] = p;
             dp[qs][kt][r] = p * dp[qs][kt][r];
           }
-        }
-        if (ragged) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if ((q0 + qo + r) >= N) {
-#pragma unroll
-              for (int kt = 0; kt < 2; ++kt) { sc[qs][kt][r] = 0.f; dp[qs][kt][r] = 0.f; }
-            }
         }
       }
       Frag<T> pa[2], da[2];
