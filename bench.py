@@ -120,7 +120,7 @@ def calibrate_teacher(model, batch, n_sup, n_unsup, target):
             hi = gain
         if abs(r - target) < 0.03:
             break
-    return gain
+    return gain, base
 
 
 def main():
@@ -167,8 +167,19 @@ def main():
     if n_unsup:
         # every rank calibrates on the SAME batch (rank 0's): the teacher replicas stay bit-identical
         calib = batches[0] if rank == 0 else synthetic_batch(1999, n_sup, n_unsup, img=img, num_classes=ncls, device=dev, **bkw)
-        seg_gain = calibrate_teacher(model, calib, n_sup, n_unsup, args.mask_ratio)
+        seg_gain, seg_base = calibrate_teacher(model, calib, n_sup, n_unsup, args.mask_ratio)
         del calib
+        if world > 1:
+            # split-K fp32 atomics make the teacher logits differ in their last bits from run to run, so two ranks can leave the
+            # bisection with different gains: rank 0's is the one every replica uses (the teachers stay bit-identical)
+            g = torch.tensor([seg_gain], device=dev, dtype=torch.float64)
+            dist.broadcast(g, 0)
+            seg_gain = float(g)
+            with torch.no_grad():
+                model.decode_head_ema.conv_seg.weight.copy_(seg_base * seg_gain)
+            model.teacher_store.mark_dirty()
+            model.ensure_engine(dev)
+        del seg_base
 
     def step(it):
         imgs, gt, metas = batches[it % 2]
@@ -220,6 +231,15 @@ def main():
     ips = world * (n_sup + n_unsup) * args.steps / dt
     gflop_step = step_gflop(n_sup, n_unsup, img=img, num_classes=ncls, pseudo_loss=True)
     step_tflops = gflop_step * args.steps / dt / 1e3          # per GPU
+
+    # ---- host cost of one step, measured from an IDLE device (nothing queued: no back-pressure from a full HIP queue in it);
+    # host_enqueue_ms_per_step above is the average inside the timed region, where submits can block on the queue
+    torch.cuda.synchronize()
+    th = time.perf_counter()
+    step(it)                                       # (every rank: the step contains collectives)
+    it += 1
+    host_idle_ms = 1e3 * (time.perf_counter() - th)
+    torch.cuda.synchronize()
 
     # ---- live per-kernel durations (HIP events on the launch stream) for the dominant kernel
     roofline = None
@@ -282,7 +302,8 @@ def main():
                                 dist_backend=dist.get_backend() if world > 1 else None,
                                 ranks_seen=dist.get_world_size() if world > 1 else 1),
                     roofline=roofline, cpu_baseline=cpu, losses=losses, mask_ratio=mask_ratio,
-                    host_enqueue_ms_per_step=round(1e3 * host_dt / args.steps, 3))
+                    host_enqueue_ms_per_step=round(1e3 * host_dt / args.steps, 3),
+                    host_enqueue_idle_queue_ms=round(host_idle_ms, 3))
         if kprof is not None:
             os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
             with open(os.path.join(ROOT, 'gpurun_out', f'bench_kernels_{args.workload}_{args.dtype}.json'), 'w') as f:

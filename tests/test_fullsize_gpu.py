@@ -42,7 +42,7 @@ def _one_step(dtype, gain, n_sup, n_unsup, img, ncls):
     if not n_unsup:
         gain = 1.0
     elif gain is None:
-        gain = bench.calibrate_teacher(model, batch, n_sup, n_unsup, 0.5)
+        gain, _ = bench.calibrate_teacher(model, batch, n_sup, n_unsup, 0.5)
     else:
         with torch.no_grad():
             model.decode_head_ema.conv_seg.weight.mul_(gain)
