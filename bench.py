@@ -274,14 +274,17 @@ def main():
         gemm_calls = sum(v['calls'] for k, v in fam.items() if k.startswith('s4f_gemm'))
         peak = MFMA_PEAK_TFLOPS[args.dtype]
         traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_gemm_hbm_traffic.json')
-        if args.workload == 'semi' and args.dtype == 'bf16' and os.path.exists(tpath):
+        import glob
+        tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_gemm_hbm_traffic.json')))     # the latest round's passes
+        tpath = tfiles[-1] if tfiles else ''
+        if args.workload == 'semi' and args.dtype == 'bf16' and tpath:
             # HBM bytes per GEMM launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command
             # (separate --pmc runs, FETCH_SIZE doubled for gfx950); bench.py cannot run the profiler on itself.
             traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
         roofline = dict(bound='mfma', kernel='s4f_gemm family: g2::gemm2_kernel / g5::gemm5_kernel / g6::gemm6_kernel (dense + implicit-GEMM conv, all launches of a step)',
                         achieved=round(gemm_gflop / gemm_ms, 1), peak=peak, unit='TFLOP/s',
                         frac=round(gemm_gflop / gemm_ms / peak, 4), traffic=traffic,
+                        traffic_source=('profiles/' + os.path.basename(tpath)) if traffic is not None else None,
                         algorithmic_gflop_per_launch=round(gemm_gflop / gemm_calls, 2),
                         launches_per_step=gemm_calls, avg_launch_ms=round(gemm_ms / gemm_calls, 4),
                         share_of_step_kernel_time=round(gemm_ms / total_ms, 3),
