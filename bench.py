@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC for RCCL's intra-node transport (must be set before HIP initialises)
 os.environ.setdefault('TORCH_NCCL_HIGH_PRIORITY', '0')   # a high-priority stream opens a FIFTH hardware queue: +8 ms per step
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}      # dense peaks, /opt/skills/guides/MI355X_MICROARCH.md
 

@@ -131,9 +131,9 @@ template <typename T, int NT> struct TilePF {
 // ------------------------------------------------------------------------------------------ forward
 // block = NW waves x 16 QT queries; K/V tiles of 64 keys double-buffered in LDS, the next tile is fetched into
 // registers while the current one is consumed (one barrier per tile).  QT = query sub-tiles (16 queries) per wave: every K
-// fragment (ds_read_b128) and V fragment (two ds_read_b64_tr) read from LDS feeds QT MFMAs.  At QT = 2 the four SIMDs of a
-// CU read 128 B/clk of fragments at full MFMA rate - exactly the LDS bandwidth, which is what held the kernel at 25 % MFMA
-// busy; QT = 4 halves the LDS bytes per MFMA (64 accumulator registers for S^T, 64 for O, two waves per SIMD).
+// fragment (ds_read_b128) and V fragment (two ds_read_b64_tr) read from LDS feeds QT MFMAs.  QT = 2 is what ships; QT = 4
+// (half the LDS bytes per MFMA, 64 + 64 accumulator registers, two waves per SIMD) was measured in round 2 and is NOT
+// instantiated: 125 vs 124 us - the LDS bandwidth is not what limits this kernel.
 template <typename T, int NW, bool HAS_BIAS, int QT>
 __global__ __launch_bounds__(64 * NW, (QT == 4) ? 2 : ((NW == 8 && sizeof(T) == 2) ? 3 : ((NW == 4 && sizeof(T) == 2) ? 3 : 1))) void attn_fwd_kernel(const AttnArgs a) {
   using C = ACfg<T>;
@@ -900,22 +900,12 @@ int bwd_launch(const AttnArgs& a, hipStream_t st) {
   return 0;
 }
 
-// query sub-tiles per wave of the bf16 forward: S4F_ATTN_QT (2 | 4)
-static int attn_qt() {
-  static int v = [] {
-    const char* e = getenv("S4F_ATTN_QT");
-    const int n = e ? atoi(e) : 2;
-    return n == 4 ? 4 : 2;
-  }();
-  return v;
-}
-
 // waves per block: the environment variable S4F_ATTN_NW (2 | 3 | 4) overrides the default for experiments
 static int attn_nw() {
   static int v = [] {
     const char* e = getenv("S4F_ATTN_NW");
     const int n = e ? atoi(e) : 4;
-    return (n == 2 || n == 3 || n == 4 || n == 8) ? n : 4;
+    return (n == 2 || n == 3 || n == 4) ? n : 4;
   }();
   return v;
 }
@@ -939,9 +929,7 @@ S4F_API int s4f_attention_fwd(const void* qkv, void* ctx, float* lse, const floa
       dim3 grid(ceil_div(a.N, 128), a.H, a.B);
       if (a.bias_u) hipLaunchKernelGGL((attn_fwd2_kernel<4, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((attn_fwd2_kernel<4, false>), grid, dim3(256), 0, st, a);
-    } else if (attn_qt() == 4) {
-      if (nw == 2) fwd_launch<bf16_t, 2, 4>(a, st); else fwd_launch<bf16_t, 4, 4>(a, st);
-    } else if (nw == 2) fwd_launch<bf16_t, 2>(a, st); else if (nw == 3) fwd_launch<bf16_t, 3>(a, st); else if (nw == 8) fwd_launch<bf16_t, 8>(a, st); else fwd_launch<bf16_t, 4>(a, st);
+    } else if (nw == 2) fwd_launch<bf16_t, 2>(a, st); else if (nw == 3) fwd_launch<bf16_t, 3>(a, st); else fwd_launch<bf16_t, 4>(a, st);
   } else {
     fwd_launch<float, 2>(a, st);
   }
@@ -961,7 +949,7 @@ S4F_API int s4f_attention_bwd(const void* qkv, const void* ctx, const void* dctx
   const int nw = attn_nw();
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S4F_BF16) {
-    if (nw == 2) bwd_launch<bf16_t, 2>(a, st); else if (nw == 3) bwd_launch<bf16_t, 3>(a, st); else if (nw == 8) bwd_launch<bf16_t, 8>(a, st); else bwd_launch<bf16_t, 4>(a, st);
+    if (nw == 2) bwd_launch<bf16_t, 2>(a, st); else if (nw == 3) bwd_launch<bf16_t, 3>(a, st); else bwd_launch<bf16_t, 4>(a, st);
   } else {
     bwd_launch<float, 2>(a, st);
   }

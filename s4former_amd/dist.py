@@ -27,16 +27,12 @@ def init_distributed(backend=None, timeout_s=None):
             backend = os.environ.get('S4F_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if timeout_s is None:
             timeout_s = float(os.environ.get('S4F_DIST_TIMEOUT_S', '600'))
-        kw = {}
         if torch.cuda.is_available():
-            dev = local % max(1, torch.cuda.device_count())
-            torch.cuda.set_device(dev)
-            if backend == 'nccl':
-                kw['device_id'] = torch.device('cuda', dev)     # eager communicator: no lazy init inside the first step
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))     # RCCL binds its communicator to the current device
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
-        dist.init_process_group(backend=backend, rank=rank, world_size=world,
-                                timeout=datetime.timedelta(seconds=timeout_s), **kw)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')    # dmabuf IPC: what RCCL's intra-node transport needs on this driver
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     return rank, local, world
 
 
