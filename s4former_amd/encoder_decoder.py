@@ -290,6 +290,13 @@ class EncoderDecoder(BaseSegmentor):
     def student_store(self):
         return self._student_store
 
+    @staticmethod
+    def sync_gradients():
+        """Make the caller's stream wait for every stream this package writes parameter gradients on (the weight-gradient
+        side stream, the head streams).  `optimizer.step()` and the gradient reducer do this themselves; anything ELSE that
+        reads `.grad` after `loss.backward()` - gradient clipping, a logging hook of a foreign runner - calls this first."""
+        join_side_streams()
+
     @property
     def teacher_store(self):
         return self._teacher_store

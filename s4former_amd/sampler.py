@@ -38,38 +38,46 @@ class DistributedSemiBalanceSampler(torch.utils.data.Sampler):
             self.num_samples += self.size_of_dataset[-1] * self.sample_ratio[j]
         self.total_size = self.num_samples * self.num_replicas
 
+    def _quota(self):
+        """samples of every dataset in one batch of `samples_per_gpu` (the last dataset takes the remainder)"""
+        total = sum(self.sample_ratio)
+        q = [int(sr / total * self.samples_per_gpu) for sr in self.sample_ratio]
+        q[-1] = self.samples_per_gpu - sum(q[:-1])
+        return q
+
+    def _epoch_stream(self):
+        """all replicas' batches of one epoch, flattened; the order of the generator calls is the reference's"""
+        gen = torch.Generator()
+        gen.manual_seed(self.epoch)
+
+        def shuffled(ids):
+            return ids[torch.randperm(len(ids), generator=gen).numpy()]
+
+        edges = [0] + self.cumulative_sizes
+        pools, queues = [], []
+        for d in range(len(self.cumulative_sizes)):
+            pools.append(np.arange(edges[d], edges[d + 1]))
+            # the reference re-draws the permutation of EVERY dataset seen so far in each pass of this loop and keeps the last
+            # pass (with two datasets, dataset 0 is permuted twice): the generator has to advance the same way
+            queues = [shuffled(pool) for pool in pools]
+        quota = self._quota()
+        batches = []
+        for _ in range(self.max_iter_size * self.num_replicas):
+            parts = []
+            for d, need in enumerate(quota):
+                if len(queues[d]) < need:                      # exhausted: append a fresh permutation of the whole dataset
+                    queues[d] = np.concatenate((queues[d], shuffled(pools[d])))
+                parts.append(queues[d][:need])
+                queues[d] = queues[d][need:]
+            batches.append(np.concatenate(parts))
+        order = torch.randperm(len(batches), generator=gen).tolist()     # the batches travel as units
+        return np.concatenate([batches[b] for b in order])
+
     def __iter__(self):
-        g = torch.Generator()
-        g.manual_seed(self.epoch)
-        bounds = [0] + self.cumulative_sizes
-        per_dataset = []
-        for i in range(len(self.cumulative_sizes)):
-            per_dataset.append(np.array(range(bounds[i], bounds[i + 1])))
-            # (the reference re-draws the permutation of EVERY dataset collected so far in each pass of this loop and keeps the
-            # last pass: dataset 0 is permuted twice with two datasets, and the generator advances accordingly)
-            shuffled = [s[list(torch.randperm(int(s.shape[0]), generator=g).numpy())] for s in per_dataset]
-        total = []
-        batch_idx = 0
-        while batch_idx < self.max_iter_size * self.num_replicas:
-            ratio = [x / sum(self.sample_ratio) for x in self.sample_ratio]
-            ratio = [int(r * self.samples_per_gpu) for r in ratio]
-            ratio[-1] = self.samples_per_gpu - sum(ratio[:-1])
-            selected = []
-            for i in range(len(shuffled)):
-                if len(shuffled[i]) < ratio[i]:
-                    shuffled[i] = np.concatenate(
-                        (shuffled[i], per_dataset[i][list(torch.randperm(int(per_dataset[i].shape[0]), generator=g).numpy())]))
-                selected.append(shuffled[i][:ratio[i]])
-                shuffled[i] = shuffled[i][ratio[i]:]
-            total.append(np.concatenate(selected))
-            batch_idx += 1
-        indices = np.concatenate(total)
-        spg = self.samples_per_gpu
-        indices = [indices[j] for i in list(torch.randperm(len(indices) // spg, generator=g)) for j in range(i * spg, (i + 1) * spg)]
-        offset = len(self) * self.rank
-        indices = indices[offset:offset + len(self)]
-        assert len(indices) == len(self)
-        return iter(indices)
+        stream = self._epoch_stream()
+        mine = stream[len(self) * self.rank:len(self) * (self.rank + 1)]
+        assert len(mine) == len(self)
+        return iter(mine.tolist())
 
     def __len__(self):
         return self.max_iter_size * self.samples_per_gpu
