@@ -43,6 +43,42 @@ def _run(cmd, env, out_dir):
     return r
 
 
+def _run_ranks(n, port, script_args, env, out_dir):
+    """n ranks as plain child processes with the RANK / WORLD_SIZE / MASTER_* environment torch.distributed.run would set
+    (no elastic agent in between: fewer moving parts under a test harness); every child gets the hard time cap, a stalled
+    group is killed by PID and the per-rank stack dumps are printed"""
+    import time
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                 OMP_NUM_THREADS='1')
+        procs.append(subprocess.Popen([sys.executable] + script_args, cwd=ROOT, env=e, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    deadline = time.time() + CAP
+    outs = [''] * n
+    try:
+        for i, pr in enumerate(procs):
+            try:
+                outs[i], _ = pr.communicate(timeout=max(1.0, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    if q.poll() is None:
+                        q.kill()
+                for k, q in enumerate(procs):
+                    try:
+                        outs[k] = (outs[k] or '') + (q.communicate(timeout=10)[0] or '')
+                    except Exception:
+                        pass
+                pytest.fail(f'{n} ranks did not finish within {CAP} s\n' + '\n'.join(o[-2000:] for o in outs) + '\n' + _dumps(out_dir))
+    finally:
+        for q in procs:
+            if q.poll() is None:
+                q.kill()
+    bad = [(i, pr.returncode) for i, pr in enumerate(procs) if pr.returncode != 0]
+    assert not bad, f'ranks failed: {bad}\n' + '\n'.join(o[-3000:] for o in outs) + '\n' + _dumps(out_dir)
+    return outs
+
+
 def _torchrun(nproc, port, script_args):
     return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr',
             '127.0.0.1', '--master-port', str(port)] + script_args
@@ -83,7 +119,7 @@ VARIANTS = {
 def test_two_ranks_equal_one_rank_on_the_concatenated_batch(variant, flags, single, tmp_path):
     d = str(tmp_path)
     port = 29600 + sorted(VARIANTS).index(variant) * 2 + (flags == 'plain')
-    _run(_torchrun(2, port, [WORKER, '--out', d, '--flags', flags]), _env(**VARIANTS[variant]), d)
+    _run_ranks(2, port, [WORKER, '--out', d, '--flags', flags], _env(**VARIANTS[variant]), d)
     r0, r1, ref = _load(d, 0), _load(d, 1), single[flags]
     assert json.loads(str(r0['meta']))['world'] == 2
     # replicas bit-identical after two steps
@@ -114,7 +150,7 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(variant, flags, sing
 def test_two_ranks_bf16_replicas_stay_identical(tmp_path):
     """perf mode through the same path: finite losses, replicas bit-identical"""
     d = str(tmp_path)
-    _run(_torchrun(2, 29620, [WORKER, '--out', d, '--flags', 'plain', '--dtype', 'bf16']), _env(), d)
+    _run_ranks(2, 29620, [WORKER, '--out', d, '--flags', 'plain', '--dtype', 'bf16'], _env(), d)
     r0, r1 = _load(d, 0), _load(d, 1)
     for k in ('student_sha', 'mom_sha', 'teacher_sha'):
         assert str(r0[k]) == str(r1[k]), f'{k} differs between the ranks'
@@ -122,7 +158,8 @@ def test_two_ranks_bf16_replicas_stay_identical(tmp_path):
 
 
 def test_bench_two_ranks_gloo(tmp_path):
-    """bench.py's own N > 1 control flow (rank-symmetric profiled step, rank-0-only reporting, barriers) on the tiny workload"""
+    """bench.py's own N > 1 control flow (rank-symmetric profiled step, rank-0-only reporting, barriers) on the tiny workload,
+    launched exactly as the driver launches it (python -m torch.distributed.run)"""
     d = str(tmp_path)
     env = _env(S4F_BENCH_WATCHDOG='90', S4F_WATCHDOG_DIR=d, S4F_DIST_TIMEOUT_S='60')
     r = _run(_torchrun(2, 29630, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
