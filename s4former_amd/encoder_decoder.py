@@ -508,16 +508,59 @@ class EncoderDecoder(BaseSegmentor):
             timg = timg[torch.tensor(tidx, device=timg.device)]
         if not self.ema:
             raise S4FError('the teacher of this build is the EMA model (ema=True in all three SETR configs)')
+        metas = [teacher_data['img_metas'][i] for i in tidx]
         with torch.no_grad():
             # The reference switches the EMA modules to eval() around this call (encoder_decoder.py:520-524, 586).  The only
             # mode-dependent op of the teacher is the head's BatchNorm, so the same effect is had by an override flag
             # on that head instead of two walks over ~400 modules per step; module.training is what it was before.
             self.decode_head_ema._eval_override = True
             try:
-                teacher_info = self.extract_teacher_info_ema(timg, [teacher_data['img_metas'][i] for i in tidx])
+                teacher_info = self._teacher_graphed(timg, metas)
+                if teacher_info is None:
+                    teacher_info = self.extract_teacher_info_ema(timg, metas)
             finally:
                 self.decode_head_ema._eval_override = False
         return teacher_info
+
+    # The teacher pass is a fixed sequence of ~110 launches on fixed-shape inputs with no autograd and no host decision in
+    # it: after two eager steps (GEMM variants resolved, kernel attributes set) it is captured ONCE in a hipGraph and
+    # replayed - one launch per step instead of ~110 ctypes calls, and no launch gaps between its kernels.  The EMA
+    # weights it reads live at fixed arena addresses, so the graph follows every update; the input is copied into the
+    # graph's static buffer, the outputs live in the graph's memory pool until the next replay (they are consumed inside
+    # the step).  OPT-IN (S4F_TEACHER_GRAPH=1): measured on the default workload the replayed graph costs 1.0 ms per step MORE
+    # than the eager launches (33.2 vs 32.2 ms, same box, same run) although it saves ~2 ms of host time - the graph's kernel
+    # nodes do not run back to back the way stream-ordered launches do on this runtime - so it only pays on a host-bound
+    # box.  A failed capture falls back to the eager path with one warning.
+    def _teacher_graphed(self, timg, metas):
+        if os.environ.get('S4F_TEACHER_GRAPH', '0') != '1' or not timg.is_cuda:
+            return None
+        st = self.__dict__.setdefault('_tgraph', dict(seen={}, graphs={}, off=False))
+        if st['off']:
+            return None
+        key = (tuple(timg.shape), runtime.compute_dtype(), getattr(self._teacher_store, 'generation', 0),
+               float(self.unsup_confidence), timg.device.index)
+        if key not in st['graphs']:
+            st['seen'][key] = st['seen'].get(key, 0) + 1
+            if st['seen'][key] <= 2:
+                return None                                   # eager warm-up steps
+            try:
+                static_in = torch.empty_like(timg)
+                static_in.copy_(timg)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    info = self.extract_teacher_info_ema(static_in, metas)
+                st['graphs'] = {key: (g, static_in, info)}    # one shape at a time: a new shape drops the old graph's pool
+            except Exception as e:                            # noqa: BLE001 - any capture failure means: stay eager
+                import warnings
+                warnings.warn(f'teacher hipGraph capture failed ({type(e).__name__}: {e}); the teacher pass stays eager')
+                st['off'] = True
+                torch.cuda.synchronize()
+                return None
+        g, static_in, info = st['graphs'][key]
+        static_in.copy_(timg)
+        g.replay()
+        return dict(info, img_metas=metas)
 
     def _fused_step(self, data_groups):
         sup, stu = data_groups['sup'], data_groups['unsup_student']

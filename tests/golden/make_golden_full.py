@@ -2,7 +2,7 @@
 
   full_sup    DeiT-B / SETR-PUP 512x512, 21 classes, 2 labelled images            (BASELINE cfg1 / cfg2 shapes), iterations 0-1
   full_pasa   the same model, 2 + 2 images, attn_mask_seperate_head + adaptive    (cfg3 / cfg4 shapes, the paper's PASA step), iterations 0-1
-  full_768    768x768, 19 classes, N = 2305 tokens, 1 + 1 images, forward only    (cfg5 shapes)
+  full_768    768x768, 19 classes, N = 2305 tokens, 1 + 1 images, one iteration      (cfg5 shapes)
 
 Per scenario: every named loss, the total, per-parameter gradient L2 norms, 32 strided gradient elements of EVERY parameter
 (+ the tensor's max |g|), |.|_1 of every state-dict tensor after the optimiser steps (student, BN statistics, EMA teacher),
@@ -34,7 +34,7 @@ SCENARIOS = {
     # name: (img, classes, flags, n_sup, n_unsup, lr, iterations with backward)
     'full_sup': (512, 21, dict(unsup_weight=0), 2, 0, 0.001, 2),
     'full_pasa': (512, 21, PASA, 2, 2, 0.001, 2),
-    'full_768': (768, 19, PASA, 1, 1, 0.001, 0),
+    'full_768': (768, 19, PASA, 1, 1, 0.001, 1),
 }
 SEED_W, SEED_B, NS = 1999, 3030, 32
 FRAG = 1e-3          # the stored tie set covers every logit bound up to FRAG * max |logit|

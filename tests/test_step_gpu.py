@@ -311,3 +311,26 @@ def test_optimizer_state_dict_round_trip():
     torch.cuda.synchronize()
     d = float((model.student_store.flat - model2.student_store.flat).abs().max())
     assert d <= 1e-5 * float(model.student_store.flat.abs().max()), d
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_teacher_hipgraph_matches_the_eager_teacher(dtype, monkeypatch):
+    """after two eager steps the teacher pass is captured in a hipGraph and replayed (EncoderDecoder._teacher_graphed): same
+    pseudo-labels, same losses as the eager path over five steps (weights move through EMA between the replays)"""
+    z, meta = load_gold('mt_pasa')
+    recs, labels = [], []
+    for graph in ('0', '1'):
+        monkeypatch.setenv('S4F_TEACHER_GRAPH', graph)
+        model, opt, sched = build_product(meta, dtype)
+        recs.append(run_product(model, opt, sched, meta, iters=5))
+        st = model.__dict__.get('_tgraph')
+        if graph == '1':
+            assert st is not None and not st['off'] and len(st['graphs']) == 1, 'the teacher pass was not captured'
+        else:
+            assert st is None
+    for it in range(5):
+        a, b = recs[0][it]['log'], recs[1][it]['log']
+        assert list(a) == list(b)
+        for k in a:
+            # (the student's split-K atomics make two eager runs differ by ~1e-6 already; pseudo-label flips would show as 1e-3)
+            assert abs(float(a[k]) - float(b[k])) <= (2e-5 if dtype == 'fp32' else 2e-3) * abs(float(a[k])) + 1e-7, (it, k, a[k], b[k])
