@@ -140,6 +140,18 @@ def main():
                 if not any(b[1] > b[0] for b in boxes) or not any(p.tolist() != sorted(p.tolist()) for p in perms):
                     seed_b += 10
                     continue
+            if flags.get('adaptive_attn_mask'):
+                # ... nor cut the PASA top-k through tied patches (implementation-defined choice: make_golden_full.py)
+                from tests.golden.make_golden_full import topk_boundary_tied
+                n0 = n_sup + n_unsup
+                tied = False
+                for it in range(2):
+                    bt = C.make_batch(seed_b + it, n_sup, n_unsup)
+                    tied = tied or topk_boundary_tied(probe, bt[0][n0:], copy.deepcopy(bt[2][n0:]))
+                if tied:
+                    print(f'[{name}] batch seed {seed_b}: PASA top-k boundary tied', flush=True)
+                    seed_b += 10
+                    continue
             seed_host_rng(seed_b)
             cwd = os.getcwd()
             with tempfile.TemporaryDirectory() as td:

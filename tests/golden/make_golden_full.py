@@ -58,6 +58,22 @@ def teacher_labels(ref, imgs, metas, th):
                 frag_pmax=pmax[frag].numpy().astype(np.float32))
 
 
+def topk_boundary_tied(ref, imgs, metas):
+    """does the PASA selection (vit.py:519-535: topk of the per-patch unconfidence, largest=False, k = half the patches) cut
+    through a group of EQUAL values for any image?  Which of the tied patches torch.topk returns is implementation-defined
+    (CPU: libstdc++ nth_element, GPU: radix select), so a fixture with such a tie cannot pin the flagged rows."""
+    ref.set_eval(True)
+    with torch.no_grad():
+        t = ref.extract_teacher_info_ema(imgs, metas)
+    ref.set_train(True)
+    conf = t['conf_mask'].float()
+    B, H, W = conf.shape
+    u = (1 - conf).view(B, H // 16, 16, W // 16, 16).sum((2, 4)).reshape(B, -1) / 256.0
+    k = u.shape[1] // 2
+    s = torch.sort(u, dim=1).values
+    return bool((s[:, k - 1] == s[:, k]).any())
+
+
 def calibrate_gain(ref, base_w, imgs, metas, target=0.5):
     """teacher conv_seg gain (bisection on the reference's own teacher pass) so that about half the pixels are confident"""
     lo, hi, gain = 1.0, 1e4, 1.0
@@ -83,7 +99,8 @@ def main():
         t0 = time.time()
         cfg = C.deit_b_cfg(img=img, num_classes=ncls, **flags)
         nb = max(iters, 1)
-        batches = [C.make_batch(SEED_B + it, n_sup, n_unsup, img=img, num_classes=ncls, block=32, border=8) for it in range(nb)]
+        seed_b = SEED_B
+        batches = [C.make_batch(seed_b + it, n_sup, n_unsup, img=img, num_classes=ncls, block=32, border=8) for it in range(nb)]
         ref = RH.build_reference_segmentor(cfg)
         ref.train()
         vals = C.load_filled(ref, SEED_W, 1.0)
@@ -93,6 +110,12 @@ def main():
             gain = calibrate_gain(ref, vals['decode_head_ema.conv_seg.weight'].clone(), batches[0][0][n0:], batches[0][2][n0:])
             gain = float(np.float32(gain))
             vals = C.load_filled(ref, SEED_W, gain)          # exactly what the GPU side will build from (seed, gain)
+            # At 1024 / 2304 patches with confidences in multiples of 1/256 the PASA top-k boundary is tied for almost every batch
+            # (a tie-free seed for one iteration took 65 tries and did not survive the EMA step of the next): the full-size
+            # fixtures are NOT tie-free; the fp32 test takes the reference CPU path's choice among tied patches
+            # (S4F_TOPK_TIES=cpu) when it compares with them.
+            print(f'[{name}] PASA top-k boundary tied at the first teacher pass: '
+                  f'{[topk_boundary_tied(ref, b[0][n0:], b[2][n0:]) for b in batches]}', flush=True)
         opt = OM.build_optimizer(ref, lr)
         out = {}
         cwd = os.getcwd()
@@ -104,6 +127,7 @@ def main():
                     OM.set_poly_lr(opt, it)
                     opt.zero_grad()
                     losses = ref.forward_train(imgs, metas, gt_semantic_seg=gt, iter=it)
+
                     loss = sum(v.mean() for k, v in losses.items() if 'loss' in k)
                     lk = [k for k, v in losses.items() if isinstance(v, torch.Tensor)]
                     out[f'it{it}_loss_keys'] = np.array(lk)
@@ -129,7 +153,7 @@ def main():
             from tests.golden.make_golden import fp64_grad_samples
             keys0 = [str(k) for k in out['it0_gn_keys']]
             del opt
-            g64 = fp64_grad_samples(cfg, SEED_W, gain, batches[0], NS)
+            g64 = fp64_grad_samples(cfg, SEED_W, gain, batches[0], NS, rng_seed=seed_b)
             gs64 = np.zeros((len(keys0), NS), dtype=np.float64)
             for i, n in enumerate(keys0):
                 gs64[i, :g64[n][0].size] = g64[n][0]
@@ -152,7 +176,7 @@ def main():
             out['teacher_frag_idx'], out['teacher_frag_margin'], out['teacher_frag_pmax'] = t['frag_idx'], t['frag_margin'], t['frag_pmax']
             print(f'[{name}] mask_ratio {t["ratio"]:.3f}, tie set {t["frag_idx"].size} of {t["label"].size} pixels', flush=True)
         out['meta'] = json.dumps(dict(scenario=name, img=img, num_classes=ncls, flags=flags, n_sup=n_sup, n_unsup=n_unsup, lr=lr,
-                                      gain=gain, seed_w=SEED_W, seed_b=SEED_B, ns=NS, frag=FRAG, iters=iters, torch=torch.__version__,
+                                      gain=gain, seed_w=SEED_W, seed_b=seed_b, ns=NS, frag=FRAG, iters=iters, torch=torch.__version__,
                                       input_sha=[C.sha(b[0]) for b in batches],
                                       weight_sha=C.sha(torch.cat([vals[k].flatten().float() for k in list(vals)[:40]]))))
         np.savez_compressed(os.path.join(HERE, f'{name}.npz'), **out)

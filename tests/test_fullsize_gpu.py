@@ -185,9 +185,15 @@ def _golden_run(name, dtype):
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 @pytest.mark.parametrize('name', ['full_sup', 'full_pasa', 'full_768'])
-def test_fullsize_step_vs_reference_golden(name, dtype):
+def test_fullsize_step_vs_reference_golden(name, dtype, monkeypatch):
     import s4former_amd as S
     from tests import common as C
+    if dtype == 'fp32' and name != 'full_sup':
+        # PASA flags the less-confident half of the patches with torch.topk; at 1024 / 2304 patches the boundary value is tied
+        # for these batches, and WHICH tied patch is returned is implementation-defined (CPU nth_element vs GPU radix select).
+        # To compare with the CPU reference the tied choice is taken from the CPU implementation (a debugging switch of the
+        # product: the default path selects on the device, as the bf16 runs of this test do).
+        monkeypatch.setenv('S4F_TOPK_TIES', 'cpu')
     try:
         z, meta, rec, info, sd = _golden_run(name, dtype)
     finally:

@@ -315,22 +315,43 @@ def test_optimizer_state_dict_round_trip():
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_teacher_hipgraph_matches_the_eager_teacher(dtype, monkeypatch):
-    """after two eager steps the teacher pass is captured in a hipGraph and replayed (EncoderDecoder._teacher_graphed): same
-    pseudo-labels, same losses as the eager path over five steps (weights move through EMA between the replays)"""
+    """S4F_TEACHER_GRAPH=1: after two eager steps the teacher pass is captured in a hipGraph and replayed
+    (EncoderDecoder._teacher_graphed).  A replay must equal the eager teacher on the same input at the CURRENT weights - also
+    after the weights have moved (EMA steps, an external edit) and for a new input - up to the split-K atomics noise of two
+    eager runs."""
+    monkeypatch.setenv('S4F_TEACHER_GRAPH', '1')
     z, meta = load_gold('mt_pasa')
-    recs, labels = [], []
-    for graph in ('0', '1'):
-        monkeypatch.setenv('S4F_TEACHER_GRAPH', graph)
-        model, opt, sched = build_product(meta, dtype)
-        recs.append(run_product(model, opt, sched, meta, iters=5))
-        st = model.__dict__.get('_tgraph')
-        if graph == '1':
-            assert st is not None and not st['off'] and len(st['graphs']) == 1, 'the teacher pass was not captured'
-        else:
-            assert st is None
-    for it in range(5):
-        a, b = recs[0][it]['log'], recs[1][it]['log']
-        assert list(a) == list(b)
-        for k in a:
-            # (the student's split-K atomics make two eager runs differ by ~1e-6 already; pseudo-label flips would show as 1e-3)
-            assert abs(float(a[k]) - float(b[k])) <= (2e-5 if dtype == 'fp32' else 2e-3) * abs(float(a[k])) + 1e-7, (it, k, a[k], b[k])
+    model, opt, sched = build_product(meta, dtype)
+    rec = run_product(model, opt, sched, meta, iters=4)
+    st = model.__dict__.get('_tgraph')
+    assert st is not None and not st['off'] and len(st['graphs']) == 1, 'the teacher pass was not captured'
+    assert all(np.isfinite(float(v)) for v in rec[-1]['log'].values())
+    n0 = meta['n_sup'] + meta['n_unsup']
+
+    def both(seed):
+        imgs, gt, metas = C.make_batch(seed, meta['n_sup'], meta['n_unsup'])
+        timg = imgs[n0:].cuda()
+        with torch.no_grad():
+            model.decode_head_ema._eval_override = True
+            try:
+                g = model._teacher_graphed(timg, metas[n0:])
+                assert g is not None, 'replay expected'
+                g = {k: v.clone() for k, v in g.items() if torch.is_tensor(v)}
+                e = model.extract_teacher_info_ema(timg, metas[n0:])
+            finally:
+                model.decode_head_ema._eval_override = False
+        torch.cuda.synchronize()
+        lg, le = g['seg_logits_lowres'].float(), e['seg_logits_lowres'].float()
+        tol = (1e-5 if dtype == 'fp32' else 2e-2) * float(le.abs().max())
+        assert float((lg - le).abs().max()) <= tol, (seed, float((lg - le).abs().max()), tol)
+        mism = float((g['hard_seg_label'] != e['hard_seg_label']).float().mean())
+        assert mism <= (1e-3 if dtype == 'fp32' else 2e-2), (seed, mism)
+        return le
+
+    a = both(meta['seed_b'] + 7)                      # a new input through the static buffer
+    with torch.no_grad():                             # the weights move: the graph reads them at their fixed arena addresses
+        model.decode_head_ema.conv_seg.weight.mul_(1.5)
+    model.teacher_store.mark_dirty()
+    model.ensure_engine(torch.device('cuda', 0))
+    b = both(meta['seed_b'] + 7)
+    assert float((b - a).abs().max()) > 0.1 * float(a.abs().max()), 'the replay did not see the new weights'
