@@ -31,6 +31,8 @@ def main():
     ap.add_argument('--n-unsup', type=int, default=4)
     ap.add_argument('--iters', type=int, default=2)
     ap.add_argument('--watchdog', type=int, default=90)
+    ap.add_argument('--rccl-one-rank', action='store_true',
+                    help='a process group of ONE rank over backend nccl (= RCCL) with every collective of the data path forced on')
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     rank = int(os.environ.get('RANK', '0'))
@@ -46,6 +48,41 @@ def main():
     from tests import common as C
 
     rank, local, world = init_distributed(timeout_s=60)
+    issued = dict(grad=0, bn=0)
+    if args.rccl_one_rank:
+        # RCCL needs one GPU per rank, so on a one-GPU box its API path (ProcessGroupNCCL's enqueue on its own stream, async work
+        # handles waited inside backward, in-place all-reduce of arena views / the SyncBN buffers / the packed log scalars) is
+        # exercised with a group of one: the all-reduce is the identity, the result must equal the plain run's.
+        import datetime
+        import s4former_amd.dist as D
+        import s4former_amd.functional as F_
+        assert world == 1
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29640')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(0)
+        try:
+            dist.init_process_group('nccl', rank=0, world_size=1, timeout=datetime.timedelta(seconds=60))
+            probe = torch.ones(8, device='cuda')
+            dist.all_reduce(probe)
+            torch.cuda.synchronize()
+        except Exception as e:                      # noqa: BLE001 - no usable RCCL on this box: the caller skips
+            print(f'RCCL-UNAVAILABLE {type(e).__name__}: {e}', flush=True)
+            sys.exit(77)
+        D.collectives_active = lambda: True
+        issue0 = D.GradReducer.issue
+
+        def _issue(t):
+            issued['grad'] += 1
+            return issue0(t)
+        D.GradReducer.issue = staticmethod(_issue)
+
+        def _reduce(self):
+            if self.buf is not None:
+                issued['bn'] += 1
+                self.issue(self.buf)
+            self.buf = None
+        F_._Exchange.reduce = _reduce
     dev = torch.device('cuda', local % torch.cuda.device_count())
     torch.cuda.set_device(dev)
     S.set_compute_dtype(args.dtype)
@@ -94,10 +131,11 @@ def main():
     rec['teacher_sha'] = np.array(hashlib.sha256(model.teacher_store.flat.cpu().numpy().tobytes()).hexdigest())
     rec['mom_sha'] = np.array(hashlib.sha256(model.student_store.mom.cpu().numpy().tobytes()).hexdigest())
     rec['nbt'] = np.array([int(v) for k, v in sd.items() if k.endswith('num_batches_tracked')])
-    rec['meta'] = np.array(json.dumps(dict(world=world, rank=rank, backend=dist.get_backend() if world > 1 else None,
+    rec['issued'] = np.array([issued['grad'], issued['bn']])
+    rec['meta'] = np.array(json.dumps(dict(world=world, rank=rank, backend=dist.get_backend() if dist.is_initialized() else None,
                                            env={k: v for k, v in os.environ.items() if k.startswith('S4F_')})))
     np.savez(os.path.join(args.out, f'rank{rank}.npz'), **rec)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()

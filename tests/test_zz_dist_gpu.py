@@ -157,6 +157,31 @@ def test_two_ranks_bf16_replicas_stay_identical(tmp_path):
     assert np.all(np.isfinite(r0['it1_loss_vals']))
 
 
+def test_one_rank_rccl_group_runs_the_data_path(single, tmp_path):
+    """the collectives of the step through backend 'nccl' (RCCL) itself - a group of ONE rank, every exchange forced on: the
+    result must equal the plain single-process run (all-reduce over one rank is the identity), and the gradient ranges and
+    SyncBN exchanges must really have been issued.  Skipped (not failed) when RCCL cannot initialise on the box."""
+    d = str(tmp_path)
+    env = _env()
+    env.pop('S4F_DIST_BACKEND')
+    try:
+        r = subprocess.run([sys.executable, WORKER, '--out', d, '--flags', 'plain', '--rccl-one-rank'], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=CAP)
+    except subprocess.TimeoutExpired as e:
+        pytest.fail(f'one-rank RCCL run timed out after {CAP} s\n{e.stdout}\n{e.stderr}\n{_dumps(d)}')
+    if r.returncode == 77:
+        pytest.skip('RCCL did not initialise on this box: ' + r.stdout[-300:])
+    assert r.returncode == 0, f'rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}\n{_dumps(d)}'
+    got, ref = _load(d, 0), single['plain']
+    assert json.loads(str(got['meta']))['backend'] == 'nccl'
+    n_grad, n_bn = (int(v) for v in got['issued'])
+    assert n_grad >= 2 * 4 and n_bn >= 2 * 10, (n_grad, n_bn)       # per step: >= one range per encoder layer, >= one exchange per BN call
+    for it in range(2):
+        assert np.allclose(got[f'it{it}_loss_vals'], ref[f'it{it}_loss_vals'], rtol=1e-6, atol=1e-7), it
+    assert np.allclose(got['state_abs_sum'], ref['state_abs_sum'], rtol=2e-6, atol=1e-7)
+    assert np.array_equal(got['nbt'], ref['nbt'])
+
+
 def test_bench_two_ranks_gloo(tmp_path):
     """bench.py's own N > 1 control flow (rank-symmetric profiled step, rank-0-only reporting, barriers) on the tiny workload,
     launched exactly as the driver launches it (python -m torch.distributed.run)"""
