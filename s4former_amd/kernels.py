@@ -140,7 +140,11 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
                 hints += [10]                        # weight-gradient form of the ping-pong kernel (gemm6.hip)
             bk = 64
             nk = (K + bk - 1) // bk
-            sks = sorted({max(1, min(nk, s_)) for s_ in ((splitk // 2, splitk, splitk * 2, splitk * 4) if atomic else (splitk,))})
+            t256 = ((M + 255) // 256) * ((N + 255) // 256)
+            # around the caller's estimate, plus the splits that put exactly one / two blocks of the 256 x 256 kernels on each of
+            # the 256 CUs (conv weight gradients: 9 tiles x 28 splits = 252 blocks beat 9 x 21 by 3 - 9 %)
+            sks = sorted({max(1, min(nk, s_)) for s_ in ((splitk // 2, splitk, splitk * 2, splitk * 4, 256 // t256, 512 // t256)
+                                                         if atomic else (splitk,))})
             tmp = torch.empty_like(out_f32) if (atomic and out_f32 is not None) else None
 
             def run(h, sk):

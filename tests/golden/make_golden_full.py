@@ -3,6 +3,7 @@
   full_sup    DeiT-B / SETR-PUP 512x512, 21 classes, 2 labelled images            (BASELINE cfg1 / cfg2 shapes), iterations 0-1
   full_pasa   the same model, 2 + 2 images, attn_mask_seperate_head + adaptive    (cfg3 / cfg4 shapes, the paper's PASA step), iterations 0-1
   full_768    768x768, 19 classes, N = 2305 tokens, 1 + 1 images, one iteration      (cfg5 shapes)
+  full_ours   full_pasa + CutMix / PatchShuffle (128-pixel blocks) + negative-class ranking  (the paper's full method), iterations 0-1
 
 Per scenario: every named loss, the total, per-parameter gradient L2 norms, 32 strided gradient elements of EVERY parameter
 (+ the tensor's max |g|), |.|_1 of every state-dict tensor after the optimiser steps (student, BN statistics, EMA teacher),
@@ -12,6 +13,7 @@ box (tests/common.py): only outputs are stored.
 
 Usage (build container):  python tests/golden/make_golden_full.py [scenario ...]
 """
+import copy
 import json
 import os
 import sys
@@ -35,6 +37,9 @@ SCENARIOS = {
     'full_sup': (512, 21, dict(unsup_weight=0), 2, 0, 0.001, 2),
     'full_pasa': (512, 21, PASA, 2, 2, 0.001, 2),
     'full_768': (768, 19, PASA, 1, 1, 0.001, 1),
+    # configs/setr/..._MT_w_ours.py:236-256 at full size: PASA + CutMix / PatchShuffle (PatchMix_N = 8: 128-pixel blocks) + NCR
+    'full_ours': (512, 21, dict(PASA, use_PatchShuffle_w_Cutmix=True, PatchMix_N=8, negative_class_ranking=True,
+                                negative_class_ranking_mode='unsup_only'), 2, 2, 0.001, 2),
 }
 SEED_W, SEED_B, NS = 1999, 3030, 32
 FRAG = 1e-3          # the stored tie set covers every logit bound up to FRAG * max |logit|
@@ -126,7 +131,9 @@ def main():
                     imgs, gt, metas = batches[it]
                     OM.set_poly_lr(opt, it)
                     opt.zero_grad()
-                    losses = ref.forward_train(imgs, metas, gt_semantic_seg=gt, iter=it)
+                    if flags.get('use_PatchShuffle_w_Cutmix'):
+                        C.seed_host_rng(seed_b + it)      # the in-model augmentations draw from the global numpy / torch generators
+                    losses = ref.forward_train(imgs, copy.deepcopy(metas), gt_semantic_seg=gt, iter=it)
 
                     loss = sum(v.mean() for k, v in losses.items() if 'loss' in k)
                     lk = [k for k, v in losses.items() if isinstance(v, torch.Tensor)]

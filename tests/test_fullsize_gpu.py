@@ -157,6 +157,7 @@ def _golden_run(name, dtype):
         assert C.sha(imgs) == meta['input_sha'][it], 'deterministic input generator drifted'
         sched.step(it)
         opt.zero_grad()
+        C.seed_host_rng(meta['seed_b'] + it)          # what the generator did before the reference's iteration ("ours" augmentations)
         out = model.train_step(dict(img=imgs.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda()), opt, iter=it)
         r = dict(log=out['log_vars'])
         if meta['iters']:
@@ -184,7 +185,7 @@ def _golden_run(name, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-@pytest.mark.parametrize('name', ['full_sup', 'full_pasa', 'full_768'])
+@pytest.mark.parametrize('name', ['full_sup', 'full_pasa', 'full_768', 'full_ours'])
 def test_fullsize_step_vs_reference_golden(name, dtype, monkeypatch):
     import s4former_amd as S
     from tests import common as C

@@ -24,8 +24,13 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-for (B, hw, cin, cout, hints, sks) in ((8, 128, 256, 256, (10,), (14, 21, 28, 42, 56)), (8, 256, 256, 256, (10,), (21, 28, 56, 84)),
-                                       (8, 64, 256, 256, (10, 4), (14, 21, 28, 56)), (8, 32, 768, 256, (4, 10), (7, 9, 14, 18, 28))):
+CASES = {
+    'semi': ((8, 128, 256, 256, (10,), (14, 21, 28, 42, 56)), (8, 256, 256, 256, (10,), (21, 28, 56, 84)),
+             (8, 64, 256, 256, (10, 4), (14, 21, 28, 56)), (8, 32, 768, 256, (4, 10), (7, 9, 14, 18, 28))),
+    'semi768': ((4, 192, 256, 256, (10,), (21, 28, 56)), (4, 384, 256, 256, (10,), (21, 28, 56)),
+                (4, 96, 256, 256, (10,), (14, 21, 28)), (4, 48, 768, 256, (4, 10), (7, 9, 14))),
+}
+for (B, hw, cin, cout, hints, sks) in CASES[sys.argv[1] if len(sys.argv) > 1 else 'semi']:
     Mk = B * hw * hw
     dy = torch.randn(Mk, cout, device='cuda').to(T)
     x = torch.randn(Mk, cin, device='cuda').to(T)
