@@ -35,6 +35,11 @@ WORKLOADS = {
              'cfg3/4: S4Former mean-teacher semi 8+8 512x512 th=0.95, pseudo-label CE enabled'),
     'semi768': (4, 4, 768, 19, dict(unsup_weight=1.0, plain_mt_pseudo_loss=True),
                 'cfg5: S4Former Cityscapes 768x768 4+4, pseudo-label CE enabled'),
+    # not BASELINE's metric (reported in DESIGN.md only): the paper's full method, configs/setr/..._MT_w_ours.py:236-256
+    'ours': (8, 8, 512, 21, dict(unsup_weight=1.0, attn_mask_seperate_head=True, attn_mask_weight=5, adaptive_attn_mask=True,
+                                 use_PatchShuffle_w_Cutmix=True, PatchMix_N=8, negative_class_ranking=True,
+                                 negative_class_ranking_mode='unsup_only'),
+             'S4Former full method 8+8 512x512: PASA (masked + plain student pass) + CutMix / PatchShuffle + NCR'),
     # not a benchmark: the N > 1 control flow of this very script on a model that steps in milliseconds (tests/test_zz_dist_gpu.py)
     'tiny': (2, 2, 64, 21, dict(unsup_weight=1.0, plain_mt_pseudo_loss=True, **TINY), 'test-only: tiny SETR-PUP 2+2 64x64'),
 }
@@ -230,7 +235,8 @@ def main():
     mask_ratio = float(model.last_mask_ratio) if model.last_mask_ratio is not None else None
 
     ips = world * (n_sup + n_unsup) * args.steps / dt
-    gflop_step = step_gflop(n_sup, n_unsup, img=img, num_classes=ncls, pseudo_loss=True)
+    gflop_step = step_gflop(n_sup, n_unsup, img=img, num_classes=ncls, pseudo_loss=True,
+                            student_passes=2 if flags.get('attn_mask_seperate_head') else 1)
     step_tflops = gflop_step * args.steps / dt / 1e3          # per GPU
 
     # ---- host cost of one step, measured from an IDLE device (nothing queued: no back-pressure from a full HIP queue in it);

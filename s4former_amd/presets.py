@@ -75,9 +75,10 @@ def algorithmic_gflop(img=512, embed=768, layers=12, channels=256, num_classes=2
     return dict(backbone=bb / 1e9, decode=head(4, 2) / 1e9, aux=head(2, 4) / 1e9)
 
 
-def step_gflop(n_sup, n_unsup, img=512, num_classes=21, pseudo_loss=True):
+def step_gflop(n_sup, n_unsup, img=512, num_classes=21, pseudo_loss=True, student_passes=1):
+    """student_passes: 2 with attn_mask_seperate_head (the unlabeled images go through backbone + decode head masked AND plain)"""
     f = algorithmic_gflop(img=img, num_classes=num_classes)
     sup = 3 * (f['backbone'] + f['decode'] + 4 * f['aux'])
-    uns = 3 * (f['backbone'] + f['decode']) if pseudo_loss else f['backbone']
+    uns = student_passes * 3 * (f['backbone'] + f['decode']) if pseudo_loss else f['backbone']
     tea = f['backbone'] + f['decode']
     return n_sup * sup + n_unsup * (uns + tea)
