@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
                                                      int accumulate) {
   constexpr int C = NV * 256;
   constexpr int U = 2;
-  __shared__ float red[3][4][C];
+  __shared__ __attribute__((aligned(16))) float red[4][C];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int nwaves = (gridDim.x * blockDim.x) >> 6;
@@ -292,21 +292,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       }
     }
   }
-  // block reduction of dgamma / dbeta / dcolsum, then one atomic per column per block
+  // block reduction of dgamma / dbeta / dcolsum, then one atomic per column per block (ONE [4][C] buffer, 12 KiB at
+  // C = 768, used three times: a block then fits beside a block of the GEMM kernels, which hold 135 - 147 of a CU's 160 KiB)
+  auto reduce_to = [&](const f32x4 (&acc)[NV], float* __restrict__ dst) {
 #pragma unroll
-  for (int v = 0; v < NV; ++v)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      red[0][wave][v * 256 + lane * 4 + e] = dg[v][e];
-      red[1][wave][v * 256 + lane * 4 + e] = db[v][e];
-      red[2][wave][v * 256 + lane * 4 + e] = dc[v][e];
-    }
-  __syncthreads();
-  for (int c = threadIdx.x; c < C; c += 256) {
-    atomicAdd(dgamma + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-    atomicAdd(dbeta + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
-    if (dcolsum) atomicAdd(dcolsum + c, red[2][0][c] + red[2][1][c] + red[2][2][c] + red[2][3][c]);
-  }
+    for (int v = 0; v < NV; ++v) *reinterpret_cast<f32x4*>(&red[wave][v * 256 + lane * 4]) = acc[v];
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+    __syncthreads();
+  };
+  reduce_to(dg, dgamma);
+  reduce_to(db, dbeta);
+  if (dcolsum) reduce_to(dc, dcolsum);
 }
 
 template <typename T>
