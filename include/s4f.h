@@ -178,6 +178,19 @@ int s4f_bn_bwd_apply(const void* g, const void* x, const float* mean, const floa
                      const float* sums, double count, void* dx, int64_t rows, int C, int dtype,
                      const float* relu_scale, const float* relu_shift, s4f_stream stream);
 int s4f_bn_param_grads(const float* sums_local, float* dgamma, float* dbeta, int C, s4f_stream stream);
+/* Last stage of a head (conv3x3 -> BN -> ReLU -> conv_seg 1x1, setr_up_head.py:57-77 + decode_head.py cls_seg) with the
+ * conv_seg input gradient folded into the BN backward passes: d[p][c] = sum_k dlo[p][k] seg_w[k][c] is recomputed on the
+ * matrix cores from the [npix, ld_dlo] logit gradient (T; columns >= ncls are ignored) instead of being written and read
+ * back.  y T [npix, C] is the conv output (BN input), scale / shift the folded BN affine (ReLU mask: y*scale+shift > 0).
+ *   stats: sums[0:C] += sum_p g, sums[C:2C] += sum_p g * xhat  with g = d * mask           (= s4f_bn_relu_up_bwd, s = 1)
+ *   apply: dy = gamma * rstd * (g - sum_g/count - xhat * sum_gx/count)                      (= s4f_bn_bwd_apply)
+ * C in {64, 128, 192, 256}, ncls <= 32 <= ld_dlo. */
+int s4f_cls_bn_bwd_stats(const void* dlo, int ld_dlo, const void* seg_w, const void* y, const float* scale,
+                         const float* shift, const float* mean, const float* rstd, float* sums, int64_t npix, int C, int ncls,
+                         int dtype, s4f_stream stream);
+int s4f_cls_bn_bwd_apply(const void* dlo, int ld_dlo, const void* seg_w, const void* y, const float* scale,
+                         const float* shift, const float* mean, const float* rstd, const float* gamma, const float* sums,
+                         double count, void* dy, int64_t npix, int C, int ncls, int dtype, s4f_stream stream);
 
 /* ------------------------------------------------------------------------------------------- losses
  * logits_lo fp32 [B, h, w, ldc] (channels-last, first C columns valid).  The final bilinear upsample by s

@@ -552,6 +552,200 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------ conv_seg input gradient inside BN backward
+// Last stage of a head (conv -> BN -> ReLU -> conv_seg, no upsample in between): the gradient that enters the ReLU is
+// d[p][c] = sum_k dlo[p][k] W[k][c] (k < ncls <= 32), a [pixels x 32] x [32 x C] product.  The unfused path writes it to
+// HBM (268 MB at 8 x 256 x 256 pixels x 256 channels) and reads it back twice (statistics pass, apply pass); here both
+// passes recompute it with ONE 16x16x32 MFMA macro step per 16 pixels x 16 channels from the 32-column dlo rows and read
+// only y: 290 instead of 536 MB (statistics), 558 instead of 804 MB (apply), and the conv_seg input-gradient GEMM is gone.
+// Wave w of a block owns channels 64 w .. 64 w + 63.  The MFMA's M index is permuted so that lane (g, li) receives, for
+// pixel li of the group, the 8 CONSECUTIVE channels 64 w + 32 u + 8 g + e (two accumulator tiles hf = 0 / 1 of four each) -
+// exactly the 16-byte chunk of y (and of dy) it loads (stores): row 4 g' + r of tile (u, hf) is channel
+// 64 w + 32 u + 8 g' + 4 hf + r.
+template <typename T> __device__ __forceinline__ void load8(const T* p, bool valid, float (&f)[8]);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, bool valid, float (&f)[8]) {
+  bf16x8 v;
+  if (valid) v = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) f[e] = valid ? (float)v[e] : 0.f;
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, bool valid, float (&f)[8]) {
+  f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, b = a;
+  if (valid) { a = *reinterpret_cast<const f32x4*>(p); b = *reinterpret_cast<const f32x4*>(p + 4); }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { f[e] = a[e]; f[4 + e] = b[e]; }
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const float (&f)[8]);
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&f)[8]) {
+  bf16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = (bf16_t)f[e];
+  *reinterpret_cast<bf16x8*>(p) = v;
+}
+template <> __device__ __forceinline__ void store8<float>(float* p, const float (&f)[8]) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{f[0], f[1], f[2], f[3]};
+  *reinterpret_cast<f32x4*>(p + 4) = f32x4{f[4], f[5], f[6], f[7]};
+}
+
+template <typename T>
+struct ClsGrad {
+  Frag<T> fa[2][2];        // W^T tiles (u, hf), rows permuted as described above
+  int cw, g, li, ncls, ld;
+  __device__ __forceinline__ void init(const T* __restrict__ W, int C, int ncls_, int ld_) {
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    g = l >> 4; li = l & 15; cw = 64 * wave; ncls = ncls_; ld = ld_;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        const int ch = cw + 32 * u + 8 * (li >> 2) + 4 * hf + (li & 3);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = 8 * g + j;
+          frag_set<T>(fa[u][hf], j, k < ncls ? to_f32<T>(W[(long)k * C + ch]) : 0.f);
+        }
+      }
+  }
+  // dlo row of pixel p (classes 8 g .. 8 g + 7 of it), columns >= ncls and pixels >= npix read as zero
+  __device__ __forceinline__ void load_dlo(Frag<T>& fb, const T* __restrict__ dlo, long p, long npix) const {
+    float v[8];
+    load8<T>(dlo + p * ld + 8 * g, p < npix && 8 * g < ncls, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) frag_set<T>(fb, j, (8 * g + j < ncls) ? v[j] : 0.f);
+  }
+  // d[e] = gradient entering the ReLU at channel cw + 32 u + 8 g + e of the lane's pixel
+  __device__ __forceinline__ void grad(const Frag<T>& fb, int u, float (&d)[8]) const {
+    const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 d0 = mma16(fa[u][0], fb, z), d1 = mma16(fa[u][1], fb, z);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { d[e] = d0[e]; d[4 + e] = d1[e]; }
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void cls_bn_bwd_stats_kernel(const T* __restrict__ dlo, int ld, const T* __restrict__ W,
+                                                               const T* __restrict__ y, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, float* __restrict__ sums,
+                                                               long npix, int C, int ncls) {
+  constexpr int UG = 2;                  // pixel groups in flight per wave
+  ClsGrad<T> cg;
+  cg.init(W, C, ncls, ld);
+  const int g = cg.g, li = cg.li, cw = cg.cw;
+  float sc[2][8], sh[2][8], mu[2][8], rs[2][8], sg[2][8], sgx[2][8];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cw + 32 * u + 8 * g + e;
+      sc[u][e] = scale[c]; sh[u][e] = shift[c]; mu[u][e] = mean[c]; rs[u][e] = rstd[c];
+      sg[u][e] = 0.f; sgx[u][e] = 0.f;
+    }
+  const long ngroups = (npix + 15) / 16;
+  for (long grp0 = blockIdx.x; grp0 < ngroups; grp0 += (long)gridDim.x * UG) {
+    Frag<T> fb[UG];
+    float yv[UG][2][8];
+#pragma unroll
+    for (int q = 0; q < UG; ++q) {
+      const long grp = grp0 + (long)q * gridDim.x;
+      const long p = grp * 16 + li;
+      const bool live = grp < ngroups && p < npix;
+      cg.load_dlo(fb[q], dlo, live ? p : 0, live ? npix : 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) load8<T>(y + p * C + cw + 32 * u + 8 * g, live, yv[q][u]);
+    }
+#pragma unroll
+    for (int q = 0; q < UG; ++q)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float d[8];
+        cg.grad(fb[q], u, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gg = (yv[q][u][e] * sc[u][e] + sh[u][e] > 0.f) ? d[e] : 0.f;
+          sg[u][e] += gg;
+          sgx[u][e] += gg * (yv[q][u][e] - mu[u][e]) * rs[u][e];
+        }
+      }
+  }
+  // the 16 lanes of a g hold partial sums of the same 16 channels (one per pixel of the group): reduce over them, collect the
+  // block's 2 C sums in LDS and add them to the global sums with two coalesced atomic instructions per wave
+  __shared__ float red[2 * 256];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        sg[u][e] += __shfl_xor(sg[u][e], o, 64);
+        sgx[u][e] += __shfl_xor(sgx[u][e], o, 64);
+      }
+      if (li == 0) {
+        const int c = cw + 32 * u + 8 * g + e;
+        red[c] = sg[u][e];
+        red[C + c] = sgx[u][e];
+      }
+    }
+  __syncthreads();
+  for (int k = threadIdx.x; k < 2 * C; k += blockDim.x) atomicAdd(sums + k, red[k]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cls_bn_bwd_apply_kernel(const T* __restrict__ dlo, int ld, const T* __restrict__ W,
+                                                               const T* __restrict__ y, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                               const float* __restrict__ sums, float inv_count,
+                                                               T* __restrict__ dy, long npix, int C, int ncls) {
+  constexpr int UG = 2;
+  ClsGrad<T> cg;
+  cg.init(W, C, ncls, ld);
+  const int g = cg.g, li = cg.li, cw = cg.cw;
+  float sc[2][8], sh[2][8], mu[2][8], a1[2][8], a2[2][8], a3[2][8];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = cw + 32 * u + 8 * g + e;
+      const float k = gamma[c] * rstd[c];
+      sc[u][e] = scale[c]; sh[u][e] = shift[c]; mu[u][e] = mean[c];
+      a1[u][e] = k;                                          // same terms as bn_bwd_apply_kernel
+      a2[u][e] = -k * sums[c] * inv_count;
+      a3[u][e] = -k * rstd[c] * sums[C + c] * inv_count;
+    }
+  const long ngroups = (npix + 15) / 16;
+  for (long grp0 = blockIdx.x; grp0 < ngroups; grp0 += (long)gridDim.x * UG) {
+    Frag<T> fb[UG];
+    float yv[UG][2][8];
+#pragma unroll
+    for (int q = 0; q < UG; ++q) {
+      const long grp = grp0 + (long)q * gridDim.x;
+      const long p = grp * 16 + li;
+      const bool live = grp < ngroups && p < npix;
+      cg.load_dlo(fb[q], dlo, live ? p : 0, live ? npix : 0);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) load8<T>(y + p * C + cw + 32 * u + 8 * g, live, yv[q][u]);
+    }
+#pragma unroll
+    for (int q = 0; q < UG; ++q) {
+      const long grp = grp0 + (long)q * gridDim.x;
+      const long p = grp * 16 + li;
+      const bool live = grp < ngroups && p < npix;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float d[8], o[8];
+        cg.grad(fb[q], u, d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gg = (yv[q][u][e] * sc[u][e] + sh[u][e] > 0.f) ? d[e] : 0.f;
+          o[e] = a1[u][e] * gg + a2[u][e] + a3[u][e] * (yv[q][u][e] - mu[u][e]);
+        }
+        if (live) store8<T>(dy + p * C + cw + 32 * u + 8 * g, o);
+      }
+    }
+  }
+}
+
 __global__ void bn_param_grads_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -1315,6 +1509,44 @@ S4F_API int s4f_bn_bwd_apply(const void* g, const void* x, const float* mean, co
   S4F_CHECK((relu_scale == nullptr) == (relu_shift == nullptr), "s4f_bn_bwd_apply: relu_scale and relu_shift go together");
   if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)x, mean, rstd, gamma, sums, inv, (bf16_t*)dx, (long)rows, C, relu_scale, relu_shift);
   else hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const float*)g, (const float*)x, mean, rstd, gamma, sums, inv, (float*)dx, (long)rows, C, relu_scale, relu_shift);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+static int cls_bn_check(const char* who, const void* dlo, const void* w, const void* y, int64_t npix, int C, int ncls, int ld) {
+  S4F_CHECK(dlo && w && y && npix > 0, "%s: null pointer / empty input", who);
+  S4F_CHECK(C % 64 == 0 && C >= 64 && C <= 256, "%s: C=%d must be 64, 128, 192 or 256", who, C);
+  S4F_CHECK(ncls >= 1 && ncls <= 32 && ld >= 32 && ld % 8 == 0, "%s: at most 32 classes in rows of >= 32 elements (ncls=%d ld=%d)", who, ncls, ld);
+  S4F_CHECK(((uintptr_t)dlo % 16) == 0 && ((uintptr_t)y % 16) == 0, "%s: 16-B alignment", who);
+  return 0;
+}
+
+S4F_API int s4f_cls_bn_bwd_stats(const void* dlo, int ld_dlo, const void* seg_w, const void* y, const float* scale,
+                                 const float* shift, const float* mean, const float* rstd, float* sums, int64_t npix, int C,
+                                 int ncls, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_cls_bn_bwd_stats");
+  if (int rc = cls_bn_check("s4f_cls_bn_bwd_stats", dlo, seg_w, y, npix, C, ncls, ld_dlo)) return rc;
+  S4F_CHECK(scale && shift && mean && rstd && sums, "s4f_cls_bn_bwd_stats: null pointer");
+  int grid = ceil_div(ceil_div(npix, 16), 8);
+  if (grid > 1024) grid = 1024;
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(cls_bn_bwd_stats_kernel<bf16_t>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const bf16_t*)dlo, ld_dlo, (const bf16_t*)seg_w, (const bf16_t*)y, scale, shift, mean, rstd, sums, (long)npix, C, ncls);
+  else hipLaunchKernelGGL(cls_bn_bwd_stats_kernel<float>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const float*)dlo, ld_dlo, (const float*)seg_w, (const float*)y, scale, shift, mean, rstd, sums, (long)npix, C, ncls);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_cls_bn_bwd_apply(const void* dlo, int ld_dlo, const void* seg_w, const void* y, const float* scale,
+                                 const float* shift, const float* mean, const float* rstd, const float* gamma,
+                                 const float* sums, double count, void* dy, int64_t npix, int C, int ncls, int dtype,
+                                 s4f_stream stream) {
+  DT_CHECK("s4f_cls_bn_bwd_apply");
+  if (int rc = cls_bn_check("s4f_cls_bn_bwd_apply", dlo, seg_w, y, npix, C, ncls, ld_dlo)) return rc;
+  S4F_CHECK(scale && shift && mean && rstd && gamma && sums && dy && count > 0, "s4f_cls_bn_bwd_apply: bad args");
+  int grid = ceil_div(ceil_div(npix, 16), 4);
+  if (grid > 4096) grid = 4096;
+  const float inv = (float)(1.0 / count);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(cls_bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const bf16_t*)dlo, ld_dlo, (const bf16_t*)seg_w, (const bf16_t*)y, scale, shift, mean, rstd, gamma, sums, inv, (bf16_t*)dy, (long)npix, C, ncls);
+  else hipLaunchKernelGGL(cls_bn_bwd_apply_kernel<float>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const float*)dlo, ld_dlo, (const float*)seg_w, (const float*)y, scale, shift, mean, rstd, gamma, sums, inv, (float*)dy, (long)npix, C, ncls);
   S4F_LAUNCH_CHECK();
   return 0;
 }

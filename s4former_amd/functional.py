@@ -20,6 +20,7 @@ from . import kernels as K
 from ._lib import BF16, F32, S4FError
 
 SKIP_MASKED_COPY = os.environ.get('S4F_SKIP_MASKED_COPY', '1') != '0'     # A/B switch of head_backward's s = 1 stages
+FUSE_CLS_GRAD = os.environ.get('S4F_FUSE_CLS_GRAD', '1') != '0'           # A/B switch: conv_seg input gradient inside the BN backward passes
 LOGIT_LD = 32   # channel stride of the low-resolution logits buffers (>= num_classes, multiple of 8)
 
 # ---------------------------------------------------------------------------------------------- side stream
@@ -558,8 +559,16 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
     K.gemm(dlo_t, feat, ncls, cin, Mp, LOGIT_LD, cin, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=store.grad_phys(hp['seg_w']),
            ldo_f32=cin, atomic=True, splitk=_splitk(_tiles(ncls, cin), _nk(Mp, code), target=1024))
     K.colsum(dlo, LOGIT_LD, Mp, ncls, store.grad_phys(hp['seg_b']), F32)
-    dcur = torch.empty(Mp, cin, device=dev, dtype=T)
-    K.gemm(dlo_t, store.shadow(hp['seg_w']), Mp, cin, ncls, LOGIT_LD, cin, code, b_mode=K.OP_K, out_t=dcur, ldo_t=cin)
+    # The input gradient of conv_seg, dfeat = dlo W, is not materialised when the stage below is the usual conv -> BN -> ReLU
+    # without upsample: its two BN backward passes recompute it from the 32-column dlo rows on the matrix cores
+    # (s4f_cls_bn_bwd_stats / _apply; FUSE_CLS_GRAD=0: the GEMM + the generic passes)
+    last = sv['stages'][-1]
+    fuse_cls = FUSE_CLS_GRAD and SKIP_MASKED_COPY and last['s'] == 1 and last['Cc'] == cin and cin in (64, 128, 192, 256) \
+        and ncls <= 32 and LOGIT_LD >= 32
+    dcur = None
+    if not fuse_cls:
+        dcur = torch.empty(Mp, cin, device=dev, dtype=T)
+        K.gemm(dlo_t, store.shadow(hp['seg_w']), Mp, cin, ncls, LOGIT_LD, cin, code, b_mode=K.OP_K, out_t=dcur, ldo_t=cin)
     world = _world() if hp['sync_bn'] else 1
     for k in range(len(hp['convs']) - 1, -1, -1):
         cv, st = hp['convs'][k], sv['stages'][k]
@@ -567,7 +576,15 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
         Mk = Bn * h * w
         bsums = ex.alloc(2 * Cc, dev)
         dy = torch.empty(Mk, Cc, device=dev, dtype=T)
-        if s == 1 and SKIP_MASKED_COPY:
+        if dcur is None:
+            K.cls_bn_bwd_stats(dlo_t, LOGIT_LD, store.shadow(hp['seg_w']), st['y'], st['scale'], st['shift'], st['mean'],
+                               st['rstd'], bsums, Mk, Cc, ncls, code)
+            K.bn_param_grads(bsums, store.grad_phys(cv['bn_w']), store.grad_phys(cv['bn_b']), Cc)
+            yield                                            # the sums cross the ranks (lockstep heads: together)
+            K.cls_bn_bwd_apply(dlo_t, LOGIT_LD, store.shadow(hp['seg_w']), st['y'], st['scale'], st['shift'], st['mean'],
+                               st['rstd'], store.phys(cv['bn_w']), bsums, st['count'], dy, Mk, Cc, ncls, code)
+            g = None
+        elif s == 1 and SKIP_MASKED_COPY:
             # no upsample: the masked gradient g = dcur * relu' is not materialised; the statistics pass and the apply pass
             # both read (dcur, y) and re-mask on the fly
             K.bn_relu_up_bwd(dcur, st['y'], st['scale'], st['shift'], st['mean'], st['rstd'], None, bsums, Bn, h, w, Cc, 1, code)
@@ -576,10 +593,11 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
             g = torch.empty(Mk, Cc, device=dev, dtype=T)
             K.bn_relu_up_bwd(dcur, st['y'], st['scale'], st['shift'], st['mean'], st['rstd'], g, bsums, Bn, h, w, Cc, s, code)
             rs = rb = None
-        K.bn_param_grads(bsums, store.grad_phys(cv['bn_w']), store.grad_phys(cv['bn_b']), Cc)
-        yield                                                # the sums cross the ranks (lockstep heads: together)
-        K.bn_bwd_apply(g, st['y'], st['mean'], st['rstd'], store.phys(cv['bn_w']), bsums, st['count'], dy, Mk, Cc, code,
-                       relu_scale=rs, relu_shift=rb)
+        if dcur is not None:
+            K.bn_param_grads(bsums, store.grad_phys(cv['bn_w']), store.grad_phys(cv['bn_b']), Cc)
+            yield                                            # the sums cross the ranks (lockstep heads: together)
+            K.bn_bwd_apply(g, st['y'], st['mean'], st['rstd'], store.phys(cv['bn_w']), bsums, st['count'], dy, Mk, Cc, code,
+                           relu_scale=rs, relu_shift=rb)
         del g
         st['y'] = None
         # conv weight gradient [Cc][3][3][cin] += dy^T (shifted inp)

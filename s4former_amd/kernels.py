@@ -446,6 +446,29 @@ def bn_bwd_apply(g, x, mean, rstd, gamma, sums, count, dx, rows, C, dtype, relu_
          p(relu_scale), p(relu_shift), stream())
 
 
+def _cls_bn_common(what, dlo, ld_dlo, seg_w, y, npix, C, ncls, dtype, *per_channel):
+    _chk_dtype(dlo, dtype, what + ' dlo'); _chk_dtype(seg_w, dtype, what + ' seg_w'); _chk_dtype(y, dtype, what + ' y')
+    _need(dlo, npix * ld_dlo, what + ' dlo'); _need(seg_w, ncls * C, what + ' seg_w'); _need(y, npix * C, what + ' y')
+    for t in per_channel:
+        _chk_f32(t, what); _need(t, C, what)
+
+
+def cls_bn_bwd_stats(dlo, ld_dlo, seg_w, y, scale, shift, mean, rstd, sums, npix, C, ncls, dtype):
+    """statistics pass of the last head stage's BN backward with the conv_seg input gradient recomputed from dlo (include/s4f.h)"""
+    _cls_bn_common('cls_bn_bwd_stats', dlo, ld_dlo, seg_w, y, npix, C, ncls, dtype, scale, shift, mean, rstd)
+    _chk_f32(sums, 'cls_bn_bwd_stats sums'); _need(sums, 2 * C, 'cls_bn_bwd_stats sums')
+    call('s4f_cls_bn_bwd_stats', p(dlo), ld_dlo, p(seg_w), p(y), p(scale), p(shift), p(mean), p(rstd), p(sums), npix, C, ncls,
+         dtype, stream())
+
+
+def cls_bn_bwd_apply(dlo, ld_dlo, seg_w, y, scale, shift, mean, rstd, gamma, sums, count, dy, npix, C, ncls, dtype):
+    _cls_bn_common('cls_bn_bwd_apply', dlo, ld_dlo, seg_w, y, npix, C, ncls, dtype, scale, shift, mean, rstd, gamma)
+    _chk_f32(sums, 'cls_bn_bwd_apply sums'); _need(sums, 2 * C, 'cls_bn_bwd_apply sums')
+    _chk_dtype(dy, dtype, 'cls_bn_bwd_apply dy'); _need(dy, npix * C, 'cls_bn_bwd_apply dy')
+    call('s4f_cls_bn_bwd_apply', p(dlo), ld_dlo, p(seg_w), p(y), p(scale), p(shift), p(mean), p(rstd), p(gamma), p(sums),
+         float(count), p(dy), npix, C, ncls, dtype, stream())
+
+
 def bn_param_grads(sums_local, dgamma, dbeta, C):
     for t, n in ((sums_local, 2 * C), (dgamma, C), (dbeta, C)):
         _chk_f32(t, 'bn_param_grads'); _need(t, n, 'bn_param_grads')

@@ -345,6 +345,57 @@ def test_bn_relu_up(K, code, s):
     check(rmd, rm_ref, 0, 'running_mean unchanged in eval', tol=1e-6)
 
 
+@pytest.mark.parametrize('code', DTYPES)
+@pytest.mark.parametrize('C,ncls,B,h,w', [(256, 21, 2, 9, 7), (128, 19, 1, 5, 5), (64, 32, 1, 4, 8), (256, 1, 1, 3, 3)])
+def test_cls_grad_inside_bn_backward(K, code, C, ncls, B, h, w):
+    """last head stage: BN (train) -> ReLU -> conv_seg 1x1.  The fused passes recompute dfeat = dlo W from the 32-column logit
+    gradient (garbage beyond ncls must be ignored) - against autograd through the oracle's ops, and against the unfused kernels"""
+    LD = 32
+    npix = B * h * w                                      # 126 / 25 / 32 / 9: ragged 16-pixel groups
+    x = q(rnd(B, C, h, w, seed=1) * 1.5 + 0.3, code)
+    gamma, beta = rnd(C, seed=2) * 0.2 + 1.0, rnd(C, seed=3) * 0.2
+    wseg = q(rnd(ncls, C, seed=7, scale=0.2), code)
+    dlo = q(rnd(npix, ncls, seed=8), code)
+    xr, g_, b_ = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z = torch.relu(O.batchnorm_train(xr, g_, b_, torch.zeros(C), torch.ones(C)))
+    logits = to_nhwc(z).reshape(npix, C) @ wseg.t()
+    logits.backward(dlo)
+
+    rows = npix
+    xh = dev(to_nhwc(x), code)
+    sums = torch.zeros(2 * C, device='cuda')
+    K.bn_stats(xh, rows, C, sums, code)
+    scale, shift, mean, rstd = (torch.empty(C, device='cuda') for _ in range(4))
+    K.bn_finalize(sums, rows, dev(gamma), dev(beta), torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'), 0.1, 1e-5, True,
+                  scale, shift, mean, rstd, C)
+    dlo_pad = torch.full((npix, LD), float('nan'))
+    dlo_pad[:, :ncls] = dlo
+    dlo_d = dev(dlo_pad, code)
+    wd = dev(wseg, code)
+    bsums = torch.zeros(2 * C, device='cuda')
+    K.cls_bn_bwd_stats(dlo_d, LD, wd, xh, scale, shift, mean, rstd, bsums, npix, C, ncls, code)
+    dx = torch.empty(B, h, w, C, device='cuda', dtype=tdt(code))
+    K.cls_bn_bwd_apply(dlo_d, LD, wd, xh, scale, shift, mean, rstd, dev(gamma), bsums, rows, dx, npix, C, ncls, code)
+    dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    K.bn_param_grads(bsums, dgam, dbet, C)
+    check(dx, to_nhwc(xr.grad), code, 'fused conv_seg grad + bn dx', tol=2e-4 if code == 0 else 3e-2)
+    check(dgam, g_.grad, code, 'fused bn dgamma', tol=2e-4 if code == 0 else 3e-2)
+    check(dbet, b_.grad, code, 'fused bn dbeta', tol=2e-4 if code == 0 else 3e-2)
+    # the unfused kernels on the same inputs (dfeat through the GEMM, rounded to the operand type)
+    dlo_z = dlo_d.clone()
+    dlo_z[:, ncls:] = 0
+    dfeat = torch.empty(npix, C, device='cuda', dtype=tdt(code))
+    K.gemm(dlo_z, wd, npix, C, ncls, LD, C, code, b_mode=K.OP_K, out_t=dfeat, ldo_t=C)
+    bs2 = torch.zeros(2 * C, device='cuda')
+    K.bn_relu_up_bwd(dfeat, xh, scale, shift, mean, rstd, None, bs2, B, h, w, C, 1, code)
+    dx2 = torch.empty_like(dx)
+    K.bn_bwd_apply(dfeat, xh, mean, rstd, dev(gamma), bs2, rows, dx2, rows, C, code, relu_scale=scale, relu_shift=shift)
+    check(bsums, bs2.cpu(), code, 'fused vs unfused sums', tol=1e-5 if code == 0 else 2e-2)
+    check(dx, dx2.float().cpu(), code, 'fused vs unfused dx', tol=1e-5 if code == 0 else 2e-2)
+    with pytest.raises(Exception):
+        K.cls_bn_bwd_stats(dlo_d, LD, wd, xh, scale, shift, mean, rstd, bsums, npix, 96, ncls, code)       # unsupported channel count
+
+
 # ------------------------------------------------------------------------------------------------ losses
 def make_labels(B, H, W, C, seed):
     g = torch.Generator().manual_seed(seed)
