@@ -185,6 +185,11 @@ int s4f_bn_param_grads(const float* sums_local, float* dgamma, float* dbeta, int
  *   stats: sums[0:C] += sum_p g, sums[C:2C] += sum_p g * xhat  with g = d * mask           (= s4f_bn_relu_up_bwd, s = 1)
  *   apply: dy = gamma * rstd * (g - sum_g/count - xhat * sum_gx/count)                      (= s4f_bn_bwd_apply)
  * C in {64, 128, 192, 256}, ncls <= 32 <= ld_dlo. */
+/* forward of the same stage in one pass over y: logits[p][k] = seg_b[k] + sum_c relu(y[p][c] scale[c] + shift[c]) seg_w[k][c]
+ * (fp32 [npix, ld_logits], columns ncls .. 31 written as 0); feat (optional, T [npix, C]) = the activation, for the
+ * backward pass.  C % 32 == 0, C <= 512, ncls <= 32 <= ld_logits. */
+int s4f_bn_relu_cls_fwd(const void* y, const float* scale, const float* shift, const void* seg_w, const float* seg_b,
+                        float* logits, int ld_logits, void* feat, int64_t npix, int C, int ncls, int dtype, s4f_stream stream);
 int s4f_cls_bn_bwd_stats(const void* dlo, int ld_dlo, const void* seg_w, const void* y, const float* scale,
                          const float* shift, const float* mean, const float* rstd, float* sums, int64_t npix, int C, int ncls,
                          int dtype, s4f_stream stream);

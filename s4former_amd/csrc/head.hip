@@ -746,6 +746,73 @@ __global__ __launch_bounds__(256) void cls_bn_bwd_apply_kernel(const T* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------ BN + ReLU + conv_seg forward
+// Last stage of a head, forward: logits[p][k] = b[k] + sum_c relu(y[p][c] scale[c] + shift[c]) W[k][c].  One pass over y: the
+// activation z goes from the registers that normalised it straight into the MFMA as the A operand (lane (g, li): pixel li,
+// channels 32 ks + 8 g .. + 7 = the 16-byte chunk it loaded), W (32 rows, those >= ncls zero) and scale / shift sit in LDS.
+// feat (optional): z is also written for the backward pass's conv_seg weight gradient; the teacher / inference pass
+// (nothing saved) writes logits only - 268 + 67 MB instead of 268 + 268 + 268 + 67 MB at 8 x 256 x 256 x 256.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_cls_fwd_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const T* __restrict__ W,
+                                                              const float* __restrict__ bias, float* __restrict__ logits,
+                                                              int ld, T* __restrict__ feat, long npix, int C, int ncls) {
+  extern __shared__ __attribute__((aligned(16))) char cls_smem[];
+  const int wstride = C * (int)sizeof(T) + 16;                 // + 16 B: the 16 class rows a read touches fall in 16 distinct bank groups
+  char* wimg = cls_smem;                                      // [32][wstride]
+  float* scs = reinterpret_cast<float*>(cls_smem + 32 * wstride);
+  float* shs = scs + C;
+  for (int i = threadIdx.x; i < 32 * C; i += blockDim.x) {
+    const int k = i / C, c = i % C;
+    *reinterpret_cast<T*>(wimg + k * wstride + c * (int)sizeof(T)) = k < ncls ? W[(long)k * C + c] : from_f32<T>(0.f);
+  }
+  for (int c = threadIdx.x; c < C; c += blockDim.x) { scs[c] = scale[c]; shs[c] = shift[c]; }
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15, nw = blockDim.x >> 6;
+  const float b0 = (bias && li < ncls) ? bias[li] : 0.f, b1 = (bias && 16 + li < ncls) ? bias[16 + li] : 0.f;
+  const long ngroups = (npix + 15) / 16;
+  const int nks = C / 32;
+  for (long grp = (long)blockIdx.x * nw + wave; grp < ngroups; grp += (long)gridDim.x * nw) {
+    const long p = grp * 16 + li;
+    const bool live = p < npix;
+    f32x4 acc0 = f32x4{b0, b0, b0, b0}, acc1 = f32x4{b1, b1, b1, b1};
+    for (int ks0 = 0; ks0 < nks; ks0 += 4) {                   // four 16-byte loads of y in flight
+      float yv[4][8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) load8<T>(y + p * C + 32 * (ks0 + q) + 8 * g, live && ks0 + q < nks, yv[q]);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int ks = ks0 + q;
+        if (ks < nks) {                                        // wave-uniform
+          const int c0 = 32 * ks + 8 * g;
+          const f32x4 s0 = *reinterpret_cast<const f32x4*>(scs + c0), s1 = *reinterpret_cast<const f32x4*>(scs + c0 + 4);
+          const f32x4 h0 = *reinterpret_cast<const f32x4*>(shs + c0), h1 = *reinterpret_cast<const f32x4*>(shs + c0 + 4);
+          float z[8];
+          Frag<T> fz, fw0, fw1;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            z[e] = fmaxf(yv[q][e] * (e < 4 ? s0[e] : s1[e - 4]) + (e < 4 ? h0[e] : h1[e - 4]), 0.f);
+            frag_set<T>(fz, e, z[e]);
+          }
+          if (feat && live) store8<T>(feat + p * C + c0, z);
+          lds_read_lin(fw0, wimg + li * wstride + c0 * (int)sizeof(T));
+          lds_read_lin(fw1, wimg + (16 + li) * wstride + c0 * (int)sizeof(T));
+          acc0 = mma16(fz, fw0, acc0);
+          acc1 = mma16(fz, fw1, acc1);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long pr = grp * 16 + 4 * g + r;
+      if (pr < npix) {
+        logits[pr * ld + li] = acc0[r];
+        logits[pr * ld + 16 + li] = acc1[r];
+      }
+    }
+  }
+}
+
 __global__ void bn_param_grads_kernel(const float* __restrict__ sums, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -1547,6 +1614,24 @@ S4F_API int s4f_cls_bn_bwd_apply(const void* dlo, int ld_dlo, const void* seg_w,
   const float inv = (float)(1.0 / count);
   if (dtype == S4F_BF16) hipLaunchKernelGGL(cls_bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const bf16_t*)dlo, ld_dlo, (const bf16_t*)seg_w, (const bf16_t*)y, scale, shift, mean, rstd, gamma, sums, inv, (bf16_t*)dy, (long)npix, C, ncls);
   else hipLaunchKernelGGL(cls_bn_bwd_apply_kernel<float>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const float*)dlo, ld_dlo, (const float*)seg_w, (const float*)y, scale, shift, mean, rstd, gamma, sums, inv, (float*)dy, (long)npix, C, ncls);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_bn_relu_cls_fwd(const void* y, const float* scale, const float* shift, const void* seg_w, const float* seg_b,
+                                float* logits, int ld_logits, void* feat, int64_t npix, int C, int ncls, int dtype,
+                                s4f_stream stream) {
+  DT_CHECK("s4f_bn_relu_cls_fwd");
+  S4F_CHECK(y && scale && shift && seg_w && logits && npix > 0, "s4f_bn_relu_cls_fwd: null pointer / empty input");
+  S4F_CHECK(C % 32 == 0 && C >= 32 && C <= 512, "s4f_bn_relu_cls_fwd: C=%d must be a multiple of 32, <= 512", C);
+  S4F_CHECK(ncls >= 1 && ncls <= 32 && ld_logits >= 32, "s4f_bn_relu_cls_fwd: at most 32 classes in rows of >= 32 floats (ncls=%d ld=%d)", ncls, ld_logits);
+  S4F_CHECK(((uintptr_t)y % 16) == 0 && (!feat || ((uintptr_t)feat % 16) == 0), "s4f_bn_relu_cls_fwd: 16-B alignment");
+  const size_t esz = dtype == S4F_BF16 ? 2 : 4;
+  const size_t shm = 32 * (C * esz + 16) + 2 * C * sizeof(float);
+  int grid = ceil_div(ceil_div(npix, 16), 4 * 4);
+  if (grid > 2048) grid = 2048;
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_relu_cls_fwd_kernel<bf16_t>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)y, scale, shift, (const bf16_t*)seg_w, seg_b, logits, ld_logits, (bf16_t*)feat, (long)npix, C, ncls);
+  else hipLaunchKernelGGL(bn_relu_cls_fwd_kernel<float>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const float*)y, scale, shift, (const float*)seg_w, seg_b, logits, ld_logits, (float*)feat, (long)npix, C, ncls);
   S4F_LAUNCH_CHECK();
   return 0;
 }

@@ -20,6 +20,7 @@ from . import kernels as K
 from ._lib import BF16, F32, S4FError
 
 SKIP_MASKED_COPY = os.environ.get('S4F_SKIP_MASKED_COPY', '1') != '0'     # A/B switch of head_backward's s = 1 stages
+FUSE_CLS_FWD = os.environ.get('S4F_FUSE_CLS_FWD', '1') != '0'             # A/B switch: BN + ReLU + conv_seg forward in one pass
 FUSE_CLS_GRAD = os.environ.get('S4F_FUSE_CLS_GRAD', '1') != '0'           # A/B switch: conv_seg input gradient inside the BN backward passes
 LOGIT_LD = 32   # channel stride of the low-resolution logits buffers (>= num_classes, multiple of 8)
 
@@ -495,6 +496,7 @@ def _head_forward_gen(tokens, hp, store, training, save, ex):
     sv = dict(tokens=tokens, mean0=mean0, rstd0=rstd0, stages=[]) if save else None
     cur, h, w, cin = xn, gh, gw, E
     nconv = len(hp['convs'])
+    logits = None
     world = _world() if (hp['sync_bn'] and training) else 1
     for k, cv in enumerate(hp['convs']):
         Cc = cv['w'].shape[0]
@@ -523,17 +525,26 @@ def _head_forward_gen(tokens, hp, store, training, save, ex):
             K.bn_finalize(None, 0, store.phys(cv['bn_w']), store.phys(cv['bn_b']), store.phys(cv['rm']),
                           store.phys(cv['rv']), hp['bn_momentum'], hp['bn_eps'], False, scale, shift, mean, rstd, Cc)
         s = hp['up_scale'] if k < nconv - 1 else 1
-        u = torch.empty(Bn * h * s * w * s, Cc, device=dev, dtype=T)
-        K.bn_relu_up_fwd(y, scale, shift, u, Bn, h, w, Cc, s, code)
+        if k == nconv - 1 and FUSE_CLS_FWD and Cc % 32 == 0 and Cc <= 512 and hp['num_classes'] <= 32 and LOGIT_LD >= 32:
+            # last stage: BN affine + ReLU + conv_seg in ONE pass over y; the activation is written only if a backward
+            # pass will need it (the conv_seg weight gradient), never on the teacher / inference path
+            logits = torch.empty(Mp, LOGIT_LD, device=dev)
+            u = torch.empty(Mp, Cc, device=dev, dtype=T) if save else None
+            K.bn_relu_cls_fwd(y, scale, shift, store.shadow(hp['seg_w']), store.phys(hp['seg_b']), logits, LOGIT_LD, u, Mp, Cc,
+                              hp['num_classes'], code)
+        else:
+            u = torch.empty(Bn * h * s * w * s, Cc, device=dev, dtype=T)
+            K.bn_relu_up_fwd(y, scale, shift, u, Bn, h, w, Cc, s, code)
         if save:
             sv['stages'].append(dict(inp=cur, y=y, scale=scale, shift=shift, mean=mean, rstd=rstd, h=h, w=w, s=s, cin=cin,
                                      count=count, Cc=Cc))
         cur, h, w, cin = u, h * s, w * s, Cc
     ncls = hp['num_classes']
     Mp = Bn * h * w
-    logits = torch.zeros(Mp, LOGIT_LD, device=dev)
-    K.gemm(cur, store.shadow(hp['seg_w']), Mp, ncls, cin, cin, cin, code, bias=store.phys(hp['seg_b']), out_f32=logits,
-           ldo_f32=LOGIT_LD)
+    if logits is None:
+        logits = torch.zeros(Mp, LOGIT_LD, device=dev)
+        K.gemm(cur, store.shadow(hp['seg_w']), Mp, ncls, cin, cin, cin, code, bias=store.phys(hp['seg_b']), out_f32=logits,
+               ldo_f32=LOGIT_LD)
     if save:
         sv['feat'] = cur
         sv['logits'] = logits

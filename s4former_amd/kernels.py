@@ -446,6 +446,19 @@ def bn_bwd_apply(g, x, mean, rstd, gamma, sums, count, dx, rows, C, dtype, relu_
          p(relu_scale), p(relu_shift), stream())
 
 
+def bn_relu_cls_fwd(y, scale, shift, seg_w, seg_b, logits, ld_logits, feat, npix, C, ncls, dtype):
+    """last head stage forward in one pass: BN affine + ReLU + conv_seg 1x1 -> low-resolution logits (+ the activation if feat)"""
+    _chk_dtype(y, dtype, 'bn_relu_cls_fwd y'); _chk_dtype(seg_w, dtype, 'bn_relu_cls_fwd seg_w'); _chk_dtype(feat, dtype, 'bn_relu_cls_fwd feat')
+    _need(y, npix * C, 'bn_relu_cls_fwd y'); _need(seg_w, ncls * C, 'bn_relu_cls_fwd seg_w')
+    _need(feat, npix * C if feat is not None else 0, 'bn_relu_cls_fwd feat')
+    for t in (scale, shift):
+        _chk_f32(t, 'bn_relu_cls_fwd'); _need(t, C, 'bn_relu_cls_fwd')
+    _chk_f32(seg_b, 'bn_relu_cls_fwd seg_b'); _need(seg_b, ncls if seg_b is not None else 0, 'bn_relu_cls_fwd seg_b')
+    _chk_f32(logits, 'bn_relu_cls_fwd logits'); _need(logits, npix * ld_logits, 'bn_relu_cls_fwd logits')
+    call('s4f_bn_relu_cls_fwd', p(y), p(scale), p(shift), p(seg_w), p(seg_b), p(logits), ld_logits, p(feat), npix, C, ncls, dtype,
+         stream())
+
+
 def _cls_bn_common(what, dlo, ld_dlo, seg_w, y, npix, C, ncls, dtype, *per_channel):
     _chk_dtype(dlo, dtype, what + ' dlo'); _chk_dtype(seg_w, dtype, what + ' seg_w'); _chk_dtype(y, dtype, what + ' y')
     _need(dlo, npix * ld_dlo, what + ' dlo'); _need(seg_w, ncls * C, what + ' seg_w'); _need(y, npix * C, what + ' y')

@@ -396,6 +396,25 @@ def test_cls_grad_inside_bn_backward(K, code, C, ncls, B, h, w):
         K.cls_bn_bwd_stats(dlo_d, LD, wd, xh, scale, shift, mean, rstd, bsums, npix, 96, ncls, code)       # unsupported channel count
 
 
+@pytest.mark.parametrize('code', DTYPES)
+@pytest.mark.parametrize('C,ncls,npix,with_feat', [(256, 21, 126, True), (128, 19, 25, False), (32, 32, 16, True), (512, 2, 40, True)])
+def test_bn_relu_cls_forward(K, code, C, ncls, npix, with_feat):
+    """BN affine + ReLU + conv_seg 1x1 in one pass = relu(y * scale + shift) @ W^T + b, logits columns >= ncls zero"""
+    LD = 32
+    y = q(rnd(npix, C, seed=1) * 1.5 + 0.2, code)
+    scale, shift = rnd(C, seed=2) * 0.2 + 1.0, rnd(C, seed=3) * 0.3
+    wseg, bseg = q(rnd(ncls, C, seed=4, scale=0.2), code), rnd(ncls, seed=5)
+    z = q(torch.relu(y * scale + shift), code)             # the activation enters the product in the operand type
+    ref = z @ wseg.t() + bseg
+    logits = torch.full((npix, LD), float('nan'), device='cuda')
+    feat = torch.empty(npix, C, device='cuda', dtype=tdt(code)) if with_feat else None
+    K.bn_relu_cls_fwd(dev(y, code), dev(scale), dev(shift), dev(wseg, code), dev(bseg), logits, LD, feat, npix, C, ncls, code)
+    check(logits[:, :ncls], ref, code, 'bn+relu+conv_seg logits', tol=1e-5 if code == 0 else 2e-3)
+    assert float(logits[:, ncls:].abs().max()) == 0.0 if ncls < LD else True
+    if with_feat:
+        check(feat, z, code, 'activation written beside the logits', tol=1e-6 if code == 0 else 1e-2)
+
+
 # ------------------------------------------------------------------------------------------------ losses
 def make_labels(B, H, W, C, seed):
     g = torch.Generator().manual_seed(seed)

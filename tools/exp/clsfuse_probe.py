@@ -40,6 +40,12 @@ for (B, hw) in ((8, 256), (8, 128)):
     t_a = timeit(lambda: K.bn_bwd_apply(dfeat, y, mean, rstd, gamma, sums, npix, dy, npix, C, 1, relu_scale=scale, relu_shift=shift))
     f_s = timeit(lambda: K.cls_bn_bwd_stats(dlo, LD, w, y, scale, shift, mean, rstd, sums, npix, C, ncls, 1))
     f_a = timeit(lambda: K.cls_bn_bwd_apply(dlo, LD, w, y, scale, shift, mean, rstd, gamma, sums, npix, dy, npix, C, ncls, 1))
+    bias = torch.zeros(ncls, device='cuda'); logits = torch.zeros(npix, LD, device='cuda'); feat = torch.empty(npix, C, device='cuda', dtype=T)
+    t_r = timeit(lambda: K.bn_relu_up_fwd(y, scale, shift, feat, B, hw, hw, C, 1, 1))
+    t_c = timeit(lambda: K.gemm(feat, w, npix, ncls, C, C, C, 1, bias=bias, out_f32=logits, ldo_f32=LD))
+    f_f = timeit(lambda: K.bn_relu_cls_fwd(y, scale, shift, w, bias, logits, LD, feat, npix, C, ncls, 1))
+    f_n = timeit(lambda: K.bn_relu_cls_fwd(y, scale, shift, w, bias, logits, LD, None, npix, C, ncls, 1))
+    print(f'  forward: bn_relu {t_r:.1f} + conv_seg gemm {t_c:.1f} = {t_r + t_c:.1f} us | fused with feat {f_f:.1f} us, logits only {f_n:.1f} us', flush=True)
     mb = npix * C * 2 / 1e6
     print(f'{B} x {hw}^2 x {C} ({mb:.0f} MB per tensor): unfused gemm {t_gemm:.1f} + stats {t_s:.1f} + apply {t_a:.1f} = {t_gemm + t_s + t_a:.1f} us | '
           f'fused stats {f_s:.1f} ({(mb + npix * 64 / 1e6) / f_s * 1e-3:.2f} TB/s) + apply {f_a:.1f} ({(2 * mb + npix * 64 / 1e6) / f_a * 1e-3:.2f} TB/s) = {f_s + f_a:.1f} us', flush=True)
