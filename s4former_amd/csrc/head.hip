@@ -627,7 +627,7 @@ __global__ __launch_bounds__(256) void cls_bn_bwd_stats_kernel(const T* __restri
                                                                const T* __restrict__ y, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, float* __restrict__ sums,
-                                                               long npix, int C, int ncls) {
+                                                               float* __restrict__ dbias, long npix, int C, int ncls) {
   constexpr int UG = 2;                  // pixel groups in flight per wave
   ClsGrad<T> cg;
   cg.init(W, C, ncls, ld);
@@ -641,6 +641,11 @@ __global__ __launch_bounds__(256) void cls_bn_bwd_stats_kernel(const T* __restri
       sc[u][e] = scale[c]; sh[u][e] = shift[c]; mu[u][e] = mean[c]; rs[u][e] = rstd[c];
       sg[u][e] = 0.f; sgx[u][e] = 0.f;
     }
+  // conv_seg bias gradient = column sums of dlo: wave 0 already holds every dlo row of the block's groups in its B fragments
+  const bool do_bias = dbias != nullptr && cw == 0;
+  float sb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) sb[j] = 0.f;
   const long ngroups = (npix + 15) / 16;
   for (long grp0 = blockIdx.x; grp0 < ngroups; grp0 += (long)gridDim.x * UG) {
     Frag<T> fb[UG];
@@ -655,7 +660,11 @@ __global__ __launch_bounds__(256) void cls_bn_bwd_stats_kernel(const T* __restri
       for (int u = 0; u < 2; ++u) load8<T>(y + p * C + cw + 32 * u + 8 * g, live, yv[q][u]);
     }
 #pragma unroll
-    for (int q = 0; q < UG; ++q)
+    for (int q = 0; q < UG; ++q) {
+      if (do_bias) {                                       // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sb[j] += to_f32<T>(fb[q].v[j]);
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         float d[8];
@@ -667,6 +676,15 @@ __global__ __launch_bounds__(256) void cls_bn_bwd_stats_kernel(const T* __restri
           sgx[u][e] += gg * (yv[q][u][e] - mu[u][e]) * rs[u][e];
         }
       }
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sb[j] += __shfl_xor(sb[j], o, 64);
+      if (li == 0 && 8 * g + j < ncls) atomicAdd(dbias + 8 * g + j, sb[j]);
+    }
   }
   // the 16 lanes of a g hold partial sums of the same 16 channels (one per pixel of the group): reduce over them, collect the
   // block's 2 C sums in LDS and add them to the global sums with two coalesced atomic instructions per wave
@@ -1589,15 +1607,15 @@ static int cls_bn_check(const char* who, const void* dlo, const void* w, const v
 }
 
 S4F_API int s4f_cls_bn_bwd_stats(const void* dlo, int ld_dlo, const void* seg_w, const void* y, const float* scale,
-                                 const float* shift, const float* mean, const float* rstd, float* sums, int64_t npix, int C,
-                                 int ncls, int dtype, s4f_stream stream) {
+                                 const float* shift, const float* mean, const float* rstd, float* sums, float* seg_b_grad,
+                                 int64_t npix, int C, int ncls, int dtype, s4f_stream stream) {
   DT_CHECK("s4f_cls_bn_bwd_stats");
   if (int rc = cls_bn_check("s4f_cls_bn_bwd_stats", dlo, seg_w, y, npix, C, ncls, ld_dlo)) return rc;
   S4F_CHECK(scale && shift && mean && rstd && sums, "s4f_cls_bn_bwd_stats: null pointer");
   int grid = ceil_div(ceil_div(npix, 16), 8);
   if (grid > 1024) grid = 1024;
-  if (dtype == S4F_BF16) hipLaunchKernelGGL(cls_bn_bwd_stats_kernel<bf16_t>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const bf16_t*)dlo, ld_dlo, (const bf16_t*)seg_w, (const bf16_t*)y, scale, shift, mean, rstd, sums, (long)npix, C, ncls);
-  else hipLaunchKernelGGL(cls_bn_bwd_stats_kernel<float>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const float*)dlo, ld_dlo, (const float*)seg_w, (const float*)y, scale, shift, mean, rstd, sums, (long)npix, C, ncls);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(cls_bn_bwd_stats_kernel<bf16_t>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const bf16_t*)dlo, ld_dlo, (const bf16_t*)seg_w, (const bf16_t*)y, scale, shift, mean, rstd, sums, seg_b_grad, (long)npix, C, ncls);
+  else hipLaunchKernelGGL(cls_bn_bwd_stats_kernel<float>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const float*)dlo, ld_dlo, (const float*)seg_w, (const float*)y, scale, shift, mean, rstd, sums, seg_b_grad, (long)npix, C, ncls);
   S4F_LAUNCH_CHECK();
   return 0;
 }

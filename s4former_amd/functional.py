@@ -569,15 +569,16 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
     # conv_seg: dW[ncls, cin] += dlo^T feat ; db += colsum(dlo) ; dfeat = dlo W
     K.gemm(dlo_t, feat, ncls, cin, Mp, LOGIT_LD, cin, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=store.grad_phys(hp['seg_w']),
            ldo_f32=cin, atomic=True, splitk=_splitk(_tiles(ncls, cin), _nk(Mp, code), target=1024))
-    K.colsum(dlo, LOGIT_LD, Mp, ncls, store.grad_phys(hp['seg_b']), F32)
     # The input gradient of conv_seg, dfeat = dlo W, is not materialised when the stage below is the usual conv -> BN -> ReLU
     # without upsample: its two BN backward passes recompute it from the 32-column dlo rows on the matrix cores
-    # (s4f_cls_bn_bwd_stats / _apply; FUSE_CLS_GRAD=0: the GEMM + the generic passes)
+    # (s4f_cls_bn_bwd_stats / _apply; FUSE_CLS_GRAD=0: the GEMM + the generic passes); the statistics pass also leaves the
+    # conv_seg bias gradient (column sums of dlo)
     last = sv['stages'][-1]
     fuse_cls = FUSE_CLS_GRAD and SKIP_MASKED_COPY and last['s'] == 1 and last['Cc'] == cin and cin in (64, 128, 192, 256) \
         and ncls <= 32 and LOGIT_LD >= 32
     dcur = None
     if not fuse_cls:
+        K.colsum(dlo, LOGIT_LD, Mp, ncls, store.grad_phys(hp['seg_b']), F32)
         dcur = torch.empty(Mp, cin, device=dev, dtype=T)
         K.gemm(dlo_t, store.shadow(hp['seg_w']), Mp, cin, ncls, LOGIT_LD, cin, code, b_mode=K.OP_K, out_t=dcur, ldo_t=cin)
     world = _world() if hp['sync_bn'] else 1
@@ -589,7 +590,7 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
         dy = torch.empty(Mk, Cc, device=dev, dtype=T)
         if dcur is None:
             K.cls_bn_bwd_stats(dlo_t, LOGIT_LD, store.shadow(hp['seg_w']), st['y'], st['scale'], st['shift'], st['mean'],
-                               st['rstd'], bsums, Mk, Cc, ncls, code)
+                               st['rstd'], bsums, Mk, Cc, ncls, code, seg_b_grad=store.grad_phys(hp['seg_b']))
             K.bn_param_grads(bsums, store.grad_phys(cv['bn_w']), store.grad_phys(cv['bn_b']), Cc)
             yield                                            # the sums cross the ranks (lockstep heads: together)
             K.cls_bn_bwd_apply(dlo_t, LOGIT_LD, store.shadow(hp['seg_w']), st['y'], st['scale'], st['shift'], st['mean'],

@@ -373,7 +373,9 @@ def test_cls_grad_inside_bn_backward(K, code, C, ncls, B, h, w):
     dlo_d = dev(dlo_pad, code)
     wd = dev(wseg, code)
     bsums = torch.zeros(2 * C, device='cuda')
-    K.cls_bn_bwd_stats(dlo_d, LD, wd, xh, scale, shift, mean, rstd, bsums, npix, C, ncls, code)
+    dbias = torch.full((ncls,), 0.5, device='cuda')
+    K.cls_bn_bwd_stats(dlo_d, LD, wd, xh, scale, shift, mean, rstd, bsums, npix, C, ncls, code, seg_b_grad=dbias)
+    check(dbias, 0.5 + dlo.sum(0), code, 'conv_seg bias gradient from the statistics pass', tol=1e-5 if code == 0 else 1e-2)
     dx = torch.empty(B, h, w, C, device='cuda', dtype=tdt(code))
     K.cls_bn_bwd_apply(dlo_d, LD, wd, xh, scale, shift, mean, rstd, dev(gamma), bsums, rows, dx, npix, C, ncls, code)
     dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
