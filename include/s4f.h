@@ -77,14 +77,19 @@ typedef struct s4f_gemm_desc {
   int32_t atomic;           /* 1: atomicAdd into out_f32 (which the caller pre-zeroed / accumulates into) */
   /* position-embedding add (patch embed): v += pos[(m % pos_period), n] */
   int32_t pos_period;
+  int32_t tile_hint;        /* kernel selection, see below (here: fills the alignment hole in front of `pos`) */
   const float* pos;         /* fp32 [pos_period, N] or NULL */
-  /* kernel selection: 0 = automatic; 1 = 128x128 register-staged kernel; 2 = 256x128 LDS-DMA kernel;
+  /* tile_hint: 0 = automatic; 1 = 128x128 register-staged kernel; 2 = 256x128 LDS-DMA kernel;
    * 3 = 256x256 LDS-DMA kernel, 8 waves; 4 = 256x256, 16 waves; 5 = 256x256, 16 waves, K step 32, 4-stage ring
    * with counted waits; 6 = 8 waves, K step 32; 7 = 4 waves (AGPR accumulators); 8 / 9 = 256x192 tile, 16 / 8 waves
    * (row-major A with row- or k-major B only: N = 768 / 2304 of the token GEMMs).  2-9: bf16 only.  In the kernels of
    * hints 3, 4, 8, 9 a row remainder M % 256 of at most 16 rows (one cls row per image) is folded into the last tile row. */
-  int32_t tile_hint;
-} s4f_gemm_desc;
+  /* optional fp32 [N]: += column sums of the T output as stored (after the activation) - the bias gradient of the linear
+   * layer whose input gradient this GEMM produces (vit.py:99-127), taken from the output tile while it is staged instead of
+   * by a second pass over the tensor.  Only the 8-wave kernel's T-output path implements it (tile_hint 10, row-major
+   * operands, N % 256 == 0, out_t only): s4f_gemm FAILS for any other combination rather than dropping it. */
+  float* colsum;
+} s4f_gemm_desc;            /* 208 bytes (the kernels take the descriptor by value inside their argument struct) */
 
 int s4f_gemm(const s4f_gemm_desc* d, s4f_stream stream);
 

@@ -37,9 +37,10 @@ class GemmDesc(Structure):
         ('out_pre', c_void_p), ('ldo_pre', c_int64),
         ('aux', c_void_p), ('ld_aux', c_int64),
         ('act', c_int32), ('atomic', c_int32),
-        ('pos_period', c_int32), ('pos', c_void_p),
-        ('tile_hint', c_int32),
+        ('pos_period', c_int32), ('tile_hint', c_int32), ('pos', c_void_p),
+        ('colsum', c_void_p),
     ]
+assert ctypes.sizeof(GemmDesc) == 208, 'GemmDesc must mirror s4f_gemm_desc (include/s4f.h, static_assert in gemm.hip)'
 
 
 _SIGS = {

@@ -322,6 +322,8 @@ int dispatch(const s4f_gemm_desc& d, hipStream_t st) {
 
 }  // namespace
 
+static_assert(sizeof(s4f_gemm_desc) == 208, "s4f_gemm_desc changed: update _lib.GemmDesc (ctypes mirror) with it");
+
 int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn);   // gemm2.hip
 int s4f_gemm5_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm5.hip
 int s4f_gemm6_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm6.hip
@@ -380,8 +382,17 @@ S4F_API int s4f_gemm(const s4f_gemm_desc* dp, s4f_stream stream) {
   }
   const int bn = pick_tile(d);
   int rc = -100;
+  if (d.colsum) {
+    // folded into the staged bf16 output tile of the 8-wave kernel only (gemm5.hip, `plain_t`)
+    const bool ok = bn == 2048 && d.dtype == S4F_BF16 && d.a_mode != S4F_OP_K && d.b_mode == S4F_OP_ROW && d.N % 256 == 0 &&
+                    d.K % 64 == 0 && d.out_t && !d.out_f32 && !d.resid && !d.pos && !d.atomic && d.splitk <= 1 &&
+                    (d.act != S4F_ACT_NONE || !d.out_pre) && d.ldo_t % 8 == 0 && (!d.out_pre || d.ldo_pre % 8 == 0) &&
+                    (!d.aux || d.ld_aux % 8 == 0);
+    S4F_CHECK(ok, "s4f_gemm: colsum needs tile_hint 10, bf16 row-major operands, N %% 256 == 0 and a T output only");
+  }
   if (bn == 2048) rc = d.a_mode == S4F_OP_K ? s4f_gemm6_try(d, (hipStream_t)stream) : s4f_gemm5_try(d, (hipStream_t)stream);
   else if (bn) rc = s4f_gemm2_try(d, (hipStream_t)stream, bn);
+  if (d.colsum && rc == -100) S4F_FAIL(-2, "s4f_gemm: colsum requested but the 8-wave kernel does not take this problem");
   if (rc == -100) rc = d.dtype == S4F_BF16 ? dispatch<bf16_t>(d, (hipStream_t)stream) : dispatch<float>(d, (hipStream_t)stream);
   if (rc == -100) S4F_FAIL(-2, "s4f_gemm: unsupported operand mode pair (%d, %d)", d.a_mode, d.b_mode);
   S4F_LAUNCH_CHECK();

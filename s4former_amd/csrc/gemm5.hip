@@ -348,6 +348,9 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
     __syncthreads();
     constexpr int NROWS = TAIL ? 256 + TAIL_MAX : 256;
     const int act = d.act;
+    float cs[8];                                     // column sums of what this thread stores (its 8 columns never change)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #pragma unroll 4
     for (int idx = threadIdx.x; idx < NROWS * 32; idx += 512) {
       const int row = idx >> 5, cc = idx & 31;
@@ -371,6 +374,24 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
         for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * (float)z[e]);
       }
       *reinterpret_cast<bf16x8*>(out_t + (long)m * d.ldo_t + n) = v;
+      if (d.colsum) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += (float)v[e];
+      }
+    }
+    if (d.colsum) {                                  // block-uniform: 16 row groups x 256 columns through the staging buffer
+      __syncthreads();
+      float* red = reinterpret_cast<float*>(smem);
+      const int cc = threadIdx.x & 31, rg = threadIdx.x >> 5;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[rg * 256 + cc * 8 + e] = cs[e];
+      __syncthreads();
+      if (threadIdx.x < 256) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += red[r * 256 + threadIdx.x];
+        atomicAdd(d.colsum + n0 + threadIdx.x, t);
+      }
     }
     return;
   }

@@ -229,11 +229,13 @@ def _handed_colsum(g):
 
 def _dgrad(dy, w, M, N, Kd, store, code, **epi):
     """dx[M, N] = dy[M, Kd] W[Kd, N]  (W = F.linear weight [out = Kd, in = N]).  bf16: row-major x row-major against the
-    transposed shadow W^T [N][Kd] (the fastest kernel forms, incl. the 8-wave ping-pong one); fp32: W read k-major."""
+    transposed shadow W^T [N][Kd] (the fastest kernel forms, incl. the 8-wave ping-pong one); fp32: W read k-major.
+    Returns True if a requested colsum= was folded into the launch."""
     if code == BF16:
-        K.gemm(dy, store.shadow_T(w), M, N, Kd, Kd, Kd, code, **epi)
-    else:
-        K.gemm(dy, store.shadow(w), M, N, Kd, Kd, N, code, b_mode=K.OP_K, **epi)
+        return K.gemm(dy, store.shadow_T(w), M, N, Kd, Kd, Kd, code, **epi)
+    epi.pop('colsum', None)
+    K.gemm(dy, store.shadow(w), M, N, Kd, Kd, N, code, b_mode=K.OP_K, **epi)
+    return False
 
 
 def _wgrad(dy, x, M, N, rows, ldm, ldn, out, code):
@@ -344,10 +346,13 @@ class LayerFn(Function):
         else:
             store.grad_phys(bf2).add_(g2cs)
         dz = torch.empty(M, F_, device=dev, dtype=T)
-        _dgrad(g2t, w2, M, F_, E, store, code, out_t=dz, ldo_t=F_, aux=sv['z'], ld_aux=F_, act=K.ACT_GELU_BWD)
+        # (the fc1 bias gradient = column sums of dz comes out of the GEMM's staged output tile where the variant allows)
+        folded = _dgrad(g2t, w2, M, F_, E, store, code, out_t=dz, ldo_t=F_, aux=sv['z'], ld_aux=F_, act=K.ACT_GELU_BWD,
+                        colsum=store.grad_phys(bf1))
         sv['z'] = sv['a'] = None
-        with on_side(dev, dz):
-            K.colsum(dz, F_, M, F_, store.grad_phys(bf1), code)
+        if not folded:
+            with on_side(dev, dz):
+                K.colsum(dz, F_, M, F_, store.grad_phys(bf1), code)
         dxn2 = torch.empty(M, E, device=dev, dtype=T)
         _dgrad(dz, w1, M, E, F_, store, code, out_t=dxn2, ldo_t=E)
         g1 = torch.empty(Bn, N, E, device=dev)

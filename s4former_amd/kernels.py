@@ -59,6 +59,7 @@ def _chk_f32(t, what):
 # signature is seen, the tile variants (128x128 register-staged / 256x128 / 256x256 LDS-DMA) and, for split-K
 # weight gradients, a few split factors are timed with HIP events and the fastest is remembered.
 AUTOTUNE = os.environ.get('S4F_AUTOTUNE', '1') != '0'
+FOLD_COLSUM = os.environ.get('S4F_FOLD_COLSUM', '1') != '0'     # A/B switch: bias gradients out of the input-gradient GEMM's output tile
 _TUNED = {}
 # Choices measured once on an MI355X for the shapes of the BASELINE configs ship with the package (tuned_gfx950.json:
 # {repr(signature): [tile_hint, splitk]}): no tuning launches at start-up, the same kernels in every run (a profile of
@@ -121,8 +122,10 @@ def _tune_gemm(key, run, candidates):
 
 def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=1.0, bias=None, resid=None, ldr=0,
          out_f32=None, ldo_f32=0, out_t=None, ldo_t=0, out_pre=None, ldo_pre=0, aux=None, ld_aux=0, act=ACT_NONE,
-         atomic=False, splitk=1, conv=None, pos_period=0, pos=None, tile_hint=0):
-    """C[m,n] = alpha * sum_k A(m,k) B(n,k) + epilogue; see include/s4f.h. conv = (B, H, W, C, sign)."""
+         atomic=False, splitk=1, conv=None, pos_period=0, pos=None, tile_hint=0, colsum=None):
+    """C[m,n] = alpha * sum_k A(m,k) B(n,k) + epilogue; see include/s4f.h. conv = (B, H, W, C, sign).
+    colsum (fp32 [N]): += column sums of out_t, folded into the kernel where the chosen variant can (returns True), else
+    left to the caller (returns False)."""
     if tile_hint == 0 and dtype == BF16 and AUTOTUNE:
         key = (a_mode, b_mode, M, N, K, lda, ldb, conv, act, bool(atomic), out_f32 is not None, out_t is not None,
                resid is not None, splitk)
@@ -153,12 +156,17 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
                              atomic, sk, conv, pos_period, pos, h)
             choice = _tune_gemm(key, run, [(h, sk) for h in hints for sk in sks])
         tile_hint, splitk = choice
+    fold = (colsum is not None and FOLD_COLSUM and tile_hint == 10 and dtype == BF16 and a_mode != OP_K and b_mode == OP_ROW and
+            N % 256 == 0 and K % 64 == 0 and out_t is not None and out_f32 is None and resid is None and pos is None and
+            not atomic and splitk <= 1 and (act != ACT_NONE or out_pre is None) and ldo_t % 8 == 0 and
+            (out_pre is None or ldo_pre % 8 == 0) and (aux is None or ld_aux % 8 == 0))
     _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, resid, ldr, out_f32, ldo_f32, out_t, ldo_t,
-                 out_pre, ldo_pre, aux, ld_aux, act, atomic, splitk, conv, pos_period, pos, tile_hint)
+                 out_pre, ldo_pre, aux, ld_aux, act, atomic, splitk, conv, pos_period, pos, tile_hint, colsum if fold else None)
+    return fold
 
 
 def _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, resid, ldr, out_f32, ldo_f32, out_t, ldo_t,
-                 out_pre, ldo_pre, aux, ld_aux, act, atomic, splitk, conv, pos_period, pos, tile_hint):
+                 out_pre, ldo_pre, aux, ld_aux, act, atomic, splitk, conv, pos_period, pos, tile_hint, colsum=None):
     _chk_dtype(A, dtype, 'gemm A'); _chk_dtype(B, dtype, 'gemm B')
     _chk_dtype(out_t, dtype, 'gemm out_t'); _chk_dtype(out_pre, dtype, 'gemm out_pre'); _chk_dtype(aux, dtype, 'gemm aux')
     _chk_f32(bias, 'gemm bias'); _chk_f32(resid, 'gemm resid'); _chk_f32(out_f32, 'gemm out_f32'); _chk_f32(pos, 'gemm pos')
@@ -208,6 +216,8 @@ def _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, re
     d.act, d.atomic = act, 1 if atomic else 0
     d.pos_period, d.pos = pos_period, p(pos)
     d.tile_hint = tile_hint
+    _chk_f32(colsum, 'gemm colsum'); _need(colsum, N if colsum is not None else 0, 'gemm colsum')
+    d.colsum = p(colsum)
     if _collect is not None:
         _collect.append(d)
         return

@@ -289,6 +289,32 @@ def test_conv3x3(K, code, B, Cin, Cout, H, W):
     check(dw.reshape(Cout, 3, 3, Cin), wr.grad.permute(0, 2, 3, 1), code, 'conv3x3 wgrad', tol=2e-4 if code == 0 else 3e-2)
 
 
+@pytest.mark.parametrize('M,N,K_,act', [(600, 512, 128, 'gelu_bwd'), (1040, 256, 192, 'none'), (272, 768, 64, 'gelu_bwd')])
+def test_gemm_colsum_from_the_output_tile(K, M, N, K_, act):
+    """the bias gradient (column sums of the bf16 output as stored) folded into the 8-wave kernel's staged output tile; a
+    variant that cannot do it must refuse, not drop it"""
+    x, w = q(rnd(M, K_, seed=1), 1), q(rnd(N, K_, seed=2, scale=0.1), 1)
+    z = q(rnd(M, N, seed=3), 1)
+    out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    cs = torch.full((N,), 0.25, device='cuda')
+    kw = dict(aux=dev(z, 1), ld_aux=N, act=K.ACT_GELU_BWD) if act == 'gelu_bwd' else {}
+    folded = K.gemm(dev(x, 1), dev(w, 1), M, N, K_, K_, K_, 1, out_t=out, ldo_t=N, tile_hint=10, colsum=cs, **kw)
+    assert folded
+    ref = x @ w.t()
+    if act == 'gelu_bwd':
+        ref = ref.to(torch.bfloat16).float() * z
+    check(out, ref, 1, 'gemm output with the column sums folded in', tol=1e-2)
+    want = 0.25 + out.float().sum(0).cpu()
+    assert torch.allclose(cs.cpu(), want, rtol=1e-4, atol=1e-3), float((cs.cpu() - want).abs().max())
+    cs2 = torch.zeros(N, device='cuda')
+    assert K.gemm(dev(x, 1), dev(w, 1), M, N, K_, K_, K_, 1, out_t=out, ldo_t=N, tile_hint=4, colsum=cs2, **kw) is False
+    assert float(cs2.abs().max()) == 0.0                      # left to the caller
+    from s4former_amd import _lib as L
+    with pytest.raises(L.S4FError):                           # the C entry point itself refuses
+        K._gemm_launch(dev(x, 1), dev(w, 1), M, N, K_, K_, K_, 1, K.OP_ROW, K.OP_ROW, 1.0, None, None, 0, None, 0, out, N, None, 0,
+                       None, 0, K.ACT_NONE, False, 1, None, 0, None, 4, cs2)
+
+
 # ------------------------------------------------------------------------------------------------ BN + ReLU + upsample
 @pytest.mark.parametrize('code', DTYPES)
 @pytest.mark.parametrize('s', [1, 2, 4])
