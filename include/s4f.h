@@ -49,6 +49,8 @@ int s4f_version(void);
 #define S4F_ACT_NONE 0
 #define S4F_ACT_GELU 1      /* out = gelu_erf(v); out_pre (if given) = gelu'(v)  (what the backward needs)   */
 #define S4F_ACT_GELU_BWD 2  /* out = v * aux[m,n]   (aux = the gelu'(.) tensor written by S4F_ACT_GELU)      */
+#define S4F_ACT_COLSTATS 3  /* out = v; colsum has 2 N entries: [0:N] += sum_m out, [N:2N] += sum_m out^2 (the BatchNorm
+                              statistics of a conv output, setr_up_head.py:57-68 + SyncBN, from the staged output tile) */
 
 typedef struct s4f_gemm_desc {
   const void* A;

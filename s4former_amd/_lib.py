@@ -12,7 +12,7 @@ import torch
 
 F32, BF16 = 0, 1
 OP_ROW, OP_K, OP_ROW_CONV, OP_K_TAPSPLIT, OP_K_CONV = 0, 1, 2, 3, 4
-ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_BWD, ACT_COLSTATS = 0, 1, 2, 3
 
 _LIB_PATH = os.environ.get('S4F_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libs4f_hip.so')   # S4F_LIB: A/B builds
 _lib = None

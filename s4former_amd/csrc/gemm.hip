@@ -382,11 +382,12 @@ S4F_API int s4f_gemm(const s4f_gemm_desc* dp, s4f_stream stream) {
   }
   const int bn = pick_tile(d);
   int rc = -100;
+  S4F_CHECK(d.act != S4F_ACT_COLSTATS || d.colsum, "s4f_gemm: S4F_ACT_COLSTATS needs colsum (2 N floats)");
   if (d.colsum) {
     // folded into the staged bf16 output tile of the 8-wave kernel only (gemm5.hip, `plain_t`)
     const bool ok = bn == 2048 && d.dtype == S4F_BF16 && d.a_mode != S4F_OP_K && d.b_mode == S4F_OP_ROW && d.N % 256 == 0 &&
                     d.K % 64 == 0 && d.out_t && !d.out_f32 && !d.resid && !d.pos && !d.atomic && d.splitk <= 1 &&
-                    (d.act != S4F_ACT_NONE || !d.out_pre) && d.ldo_t % 8 == 0 && (!d.out_pre || d.ldo_pre % 8 == 0) &&
+                    ((d.act != S4F_ACT_NONE && d.act != S4F_ACT_COLSTATS) || !d.out_pre) && d.ldo_t % 8 == 0 && (!d.out_pre || d.ldo_pre % 8 == 0) &&
                     (!d.aux || d.ld_aux % 8 == 0);
     S4F_CHECK(ok, "s4f_gemm: colsum needs tile_hint 10, bf16 row-major operands, N %% 256 == 0 and a T output only");
   }

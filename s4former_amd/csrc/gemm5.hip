@@ -348,9 +348,9 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
     __syncthreads();
     constexpr int NROWS = TAIL ? 256 + TAIL_MAX : 256;
     const int act = d.act;
-    float cs[8];                                     // column sums of what this thread stores (its 8 columns never change)
+    float cs[8], cq[8];                              // column sums (and sums of squares) of what this thread stores (its 8 columns never change)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
+    for (int e = 0; e < 8; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
 #pragma unroll 4
     for (int idx = threadIdx.x; idx < NROWS * 32; idx += 512) {
       const int row = idx >> 5, cc = idx & 31;
@@ -377,6 +377,10 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
       if (d.colsum) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) cs[e] += (float)v[e];
+        if (act == S4F_ACT_COLSTATS) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cq[e] += (float)v[e] * (float)v[e];
+        }
       }
     }
     if (d.colsum) {                                  // block-uniform: 16 row groups x 256 columns through the staging buffer
@@ -391,6 +395,18 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += red[r * 256 + threadIdx.x];
         atomicAdd(d.colsum + n0 + threadIdx.x, t);
+      }
+      if (act == S4F_ACT_COLSTATS) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rg * 256 + cc * 8 + e] = cq[e];
+        __syncthreads();
+        if (threadIdx.x < 256) {
+          float t = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t += red[r * 256 + threadIdx.x];
+          atomicAdd(d.colsum + d.N + n0 + threadIdx.x, t);
+        }
       }
     }
     return;

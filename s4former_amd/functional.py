@@ -507,6 +507,7 @@ def _head_forward_gen(tokens, hp, store, training, save, ex):
         Cc = cv['w'].shape[0]
         Mp = Bn * h * w
         y = torch.empty(Mp, Cc, device=dev, dtype=T)
+        sums, stats_done = None, False
         if code == BF16 and _tiles256(Mp, Cc) < 96:
             # few output tiles (the 32x32 stage): split the 9*cin contraction over blocks, fp32 partial sums
             yf = torch.zeros(Mp, Cc, device=dev)
@@ -514,14 +515,19 @@ def _head_forward_gen(tokens, hp, store, training, save, ex):
                    ldo_f32=Cc, atomic=True, splitk=max(2, min(16, 192 // _tiles256(Mp, Cc))), conv=(Bn, h, w, cin, 1))
             K.cast(yf, y, code)
         else:
-            K.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_t=y, ldo_t=Cc,
-                   conv=(Bn, h, w, cin, 1))
+            # training: the BatchNorm statistics (column sums and sums of squares of y as stored) come out of the conv GEMM's
+            # staged output tile where the chosen kernel variant can do that (the two large stages), else from a pass over y
+            sums = ex.alloc(2 * Cc, dev) if training else None
+            stats_done = K.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_t=y,
+                                ldo_t=Cc, conv=(Bn, h, w, cin, 1), colstats=sums)
         scale = torch.empty(Cc, device=dev); shift = torch.empty(Cc, device=dev)
         mean = torch.empty(Cc, device=dev); rstd = torch.empty(Cc, device=dev)
         count = float(Mp) * world
         if training:
-            sums = ex.alloc(2 * Cc, dev)
-            K.bn_stats(y, Mp, Cc, sums, code)
+            if sums is None:
+                sums = ex.alloc(2 * Cc, dev)
+            if not stats_done:
+                K.bn_stats(y, Mp, Cc, sums, code)
             yield                                            # the statistics cross the ranks (lockstep heads: together)
             K.bn_finalize(sums, count, store.phys(cv['bn_w']), store.phys(cv['bn_b']), store.phys(cv['rm']),
                           store.phys(cv['rv']), hp['bn_momentum'], hp['bn_eps'], True, scale, shift, mean, rstd, Cc)

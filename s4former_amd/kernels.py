@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from ._lib import (ACT_GELU, ACT_GELU_BWD, ACT_NONE, BF16, F32, OP_K, OP_K_CONV, OP_K_TAPSPLIT, OP_ROW,
+from ._lib import (ACT_COLSTATS, ACT_GELU, ACT_GELU_BWD, ACT_NONE, BF16, F32, OP_K, OP_K_CONV, OP_K_TAPSPLIT, OP_ROW,
                    OP_ROW_CONV, S4FError, call, p, stream)
 
 __all__ = ['gemm', 'wgrad_grouped', 'transpose_many', 'cast', 'cast_back', 'im2col_patch16', 'cls_pos', 'tokens_bwd', 'colsum', 'layernorm_fwd',
@@ -122,10 +122,15 @@ def _tune_gemm(key, run, candidates):
 
 def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=1.0, bias=None, resid=None, ldr=0,
          out_f32=None, ldo_f32=0, out_t=None, ldo_t=0, out_pre=None, ldo_pre=0, aux=None, ld_aux=0, act=ACT_NONE,
-         atomic=False, splitk=1, conv=None, pos_period=0, pos=None, tile_hint=0, colsum=None):
+         atomic=False, splitk=1, conv=None, pos_period=0, pos=None, tile_hint=0, colsum=None, colstats=None):
     """C[m,n] = alpha * sum_k A(m,k) B(n,k) + epilogue; see include/s4f.h. conv = (B, H, W, C, sign).
-    colsum (fp32 [N]): += column sums of out_t, folded into the kernel where the chosen variant can (returns True), else
-    left to the caller (returns False)."""
+    colsum (fp32 [N]): += column sums of out_t; colstats (fp32 [2 N], act must be ACT_NONE): += column sums and sums of squares
+    (BatchNorm statistics).  Folded into the kernel where the chosen variant can (returns True), else left to the caller
+    (returns False)."""
+    if colstats is not None:
+        if colsum is not None or act != ACT_NONE:
+            raise S4FError('gemm: colstats excludes colsum and an activation')
+        colsum = colstats
     if tile_hint == 0 and dtype == BF16 and AUTOTUNE:
         key = (a_mode, b_mode, M, N, K, lda, ldb, conv, act, bool(atomic), out_f32 is not None, out_t is not None,
                resid is not None, splitk)
@@ -160,6 +165,8 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
             N % 256 == 0 and K % 64 == 0 and out_t is not None and out_f32 is None and resid is None and pos is None and
             not atomic and splitk <= 1 and (act != ACT_NONE or out_pre is None) and ldo_t % 8 == 0 and
             (out_pre is None or ldo_pre % 8 == 0) and (aux is None or ld_aux % 8 == 0))
+    if fold and colstats is not None:
+        act = ACT_COLSTATS
     _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, resid, ldr, out_f32, ldo_f32, out_t, ldo_t,
                  out_pre, ldo_pre, aux, ld_aux, act, atomic, splitk, conv, pos_period, pos, tile_hint, colsum if fold else None)
     return fold
@@ -216,7 +223,8 @@ def _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, re
     d.act, d.atomic = act, 1 if atomic else 0
     d.pos_period, d.pos = pos_period, p(pos)
     d.tile_hint = tile_hint
-    _chk_f32(colsum, 'gemm colsum'); _need(colsum, N if colsum is not None else 0, 'gemm colsum')
+    _chk_f32(colsum, 'gemm colsum')
+    _need(colsum, (2 * N if act == ACT_COLSTATS else N) if colsum is not None else 0, 'gemm colsum')
     d.colsum = p(colsum)
     if _collect is not None:
         _collect.append(d)

@@ -315,6 +315,28 @@ def test_gemm_colsum_from_the_output_tile(K, M, N, K_, act):
                        None, 0, K.ACT_NONE, False, 1, None, 0, None, 4, cs2)
 
 
+def test_gemm_colstats_from_the_output_tile(K):
+    """BatchNorm statistics of a conv output (column sums and sums of squares of the stored bf16 values) from the GEMM's
+    staged output tile - same numbers as bn_stats over the written tensor"""
+    B, h, w, cin, cout = 2, 16, 24, 64, 256
+    Mp = B * h * w
+    x = dev(q(rnd(Mp, cin, seed=1), 1), 1)
+    wt = dev(q(rnd(cout, 9 * cin, seed=2, scale=0.05), 1), 1)
+    y = torch.empty(Mp, cout, device='cuda', dtype=torch.bfloat16)
+    sums = torch.full((2 * cout,), 1.5, device='cuda')
+    assert K.gemm(x, wt, Mp, cout, 9 * cin, cin, 9 * cin, 1, a_mode=K.OP_ROW_CONV, out_t=y, ldo_t=cout, conv=(B, h, w, cin, 1),
+                  tile_hint=10, colstats=sums)
+    ref = torch.zeros(2 * cout, device='cuda')
+    K.bn_stats(y, Mp, cout, ref, 1)
+    assert torch.allclose(sums - 1.5, ref, rtol=2e-5, atol=1e-3), float((sums - 1.5 - ref).abs().max())
+    yf = y.float()
+    assert torch.allclose(sums[:cout] - 1.5, yf.sum(0), rtol=1e-4, atol=1e-2)
+    assert torch.allclose(sums[cout:] - 1.5, (yf * yf).sum(0), rtol=1e-4, atol=1e-2)
+    y2 = torch.empty_like(y)
+    K.gemm(x, wt, Mp, cout, 9 * cin, cin, 9 * cin, 1, a_mode=K.OP_ROW_CONV, out_t=y2, ldo_t=cout, conv=(B, h, w, cin, 1), tile_hint=10)
+    assert torch.equal(y, y2)                                  # the output itself is untouched by the statistics
+
+
 # ------------------------------------------------------------------------------------------------ BN + ReLU + upsample
 @pytest.mark.parametrize('code', DTYPES)
 @pytest.mark.parametrize('s', [1, 2, 4])
