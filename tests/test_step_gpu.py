@@ -58,6 +58,26 @@ def run_product(model, opt, sched, meta, iters=2):
     return rec
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_unfused_head_paths_still_agree_with_the_golden(dtype, monkeypatch):
+    """the A/B switches of the head fusions (S4F_FUSE_CLS_FWD / _GRAD, S4F_FOLD_COLSUM) select the kernels that remain the
+    path for heads the fused kernels do not take (other channel counts, > 32 classes): those must stay correct too"""
+    import s4former_amd.functional as F_
+    import s4former_amd.kernels as K_
+    monkeypatch.setattr(F_, 'FUSE_CLS_FWD', False)
+    monkeypatch.setattr(F_, 'FUSE_CLS_GRAD', False)
+    monkeypatch.setattr(K_, 'FOLD_COLSUM', False)
+    z, meta = load_gold('mt_pasa')
+    model, opt, sched = build_product(meta, dtype)
+    rec = run_product(model, opt, sched, meta, iters=1)
+    ltol, gtol = {'fp32': (1e-4, 1e-3), 'bf16': (2e-2, 8e-2)}[dtype]
+    for k, v in zip([str(k) for k in z['it0_loss_keys']], z['it0_loss_vals']):
+        if 'loss' in k:
+            assert abs(rec[0]['log'][k] - v) <= ltol * abs(v), (k, rec[0]['log'][k], v)
+    for k, v in zip([str(k) for k in z['it0_gn_keys']], z['it0_gn_vals']):
+        assert abs(rec[0]['gn'][k] - v) <= gtol * (abs(v) + 1e-12), (k, rec[0]['gn'][k], v)
+
+
 @pytest.mark.parametrize('name', ['sup', 'mt_literal', 'mt_pasa', 'mt_ours'])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
 def test_step_vs_golden(name, dtype):
