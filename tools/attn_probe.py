@@ -23,8 +23,8 @@ def timeit(fn, iters=30):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-for (Bn, bias) in ((16, True), (16, False), (8, False)):
-    N, H = 1025, 12
+for (Bn, bias, N) in ((16, True, 1025), (16, False, 1025), (8, False, 1025), (8, True, 2305), (4, False, 2305)):
+    H = 12
     qkv = torch.randn(Bn, N, 3 * 768, device='cuda').to(T)
     ctx = torch.empty(Bn, N, 768, device='cuda', dtype=T)
     lse = torch.empty(Bn, H, N, device='cuda')
@@ -36,4 +36,4 @@ for (Bn, bias) in ((16, True), (16, False), (8, False)):
     f = timeit(lambda: K.attention_fwd(qkv, ctx, lse, Bn, N, H, 1, bias_u=bu, row_flag=fl, bias_w=5.0))
     b = timeit(lambda: K.attention_bwd(qkv, ctx, dctx, lse, delta, dqkv, Bn, N, H, 1, bias_u=bu, row_flag=fl, bias_w=5.0))
     gf = 4.0 * Bn * H * N * N * 64 / 1e9
-    print(f'B={Bn} bias={bias}: fwd {f:7.1f} us ({gf / f * 1e3:6.0f} TF/s)   bwd {b:7.1f} us ({2.5 * gf / b * 1e3:6.0f} TF/s algorithmic)', flush=True)
+    print(f'B={Bn} N={N} bias={bias}: fwd {f:7.1f} us ({gf / f * 1e3:6.0f} TF/s)   bwd {b:7.1f} us ({2.5 * gf / b * 1e3:6.0f} TF/s algorithmic)', flush=True)
