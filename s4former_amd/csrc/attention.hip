@@ -341,6 +341,10 @@ __global__ __launch_bounds__(64 * NW, (QT == 4) ? 2 : ((NW == 8 && sizeof(T) == 
 }
 
 // ------------------------------------------------------------------------------------------ dQ
+// blocks per CU the dQ kernel is compiled for: 3 (<= 168 registers; the two-halves loop below needs 158 - 179)
+#ifndef ATTN_DQ_MINB
+#define ATTN_DQ_MINB 3
+#endif
 // ------------------------------------------------------------------------------------------ forward, bf16, VALU diet
 // The forward above is bound by the SIMD's vector ISSUE port, not by the MFMA pipe or the LDS (MI355X_MICROARCH 'vector-
 // instruction ISSUE cost': an MFMA 16x16x32 holds the port 8 cycles, v_exp_f32 8, every other VALU op 4-5, and packed fp32
@@ -561,7 +565,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_fwd2_kernel(const AttnArgs a)
 }
 
 template <typename T, int NW, bool HAS_BIAS>
-__global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, ATTN_DQ_MINB) void attn_dq_kernel(const AttnArgs a) {
   using C = ACfg<T>;
   constexpr bool PRESCALE = sizeof(T) == 2;
   constexpr int NT = 64 * NW;
@@ -657,43 +661,45 @@ __global__ __launch_bounds__(64 * NW) void attn_dq_kernel(const AttnArgs a) {
     if (active) {
 
     // row constants as the initial accumulators (guide, attention backward): S' = q.k - lse / c and dP' = dO.v - delta
-    // leave the MFMA chains ready for p = exp2(c S' [+ bias]) and dS = p dP' (one subtraction per score less)
-    f32x4 st[4][2], dp[4][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        Frag<T> fk, fv;
-        tile_rowfrag<T>(fk, Ks, ks * 16 + li, s);
-        tile_rowfrag<T>(fv, Vs, ks * 16 + li, s);
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          st[ks][qt] = mma16(fk, fq[qt][s], s == 0 ? sinit[qt] : st[ks][qt]);
-          dp[ks][qt] = mma16(fv, fdo[qt][s], s == 0 ? dinit[qt] : dp[ks][qt]);
-        }
-      }
-    // (keys beyond N need no masking here: their K rows are zero in the LDS image, so whatever dS holds for them adds
-    //  nothing to dQ = dS K; p and dP' stay finite - S' = -lse, dP' = -delta)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      f32x4 uu = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (HAS_BIAS) uu = *reinterpret_cast<const f32x4*>(us + ks * 16 + 4 * g);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-          float e;
-          if constexpr (PRESCALE) e = HAS_BIAS ? fmaf(uu[r], flagq[qt], st[ks][qt][r]) : st[ks][qt][r];
-          else e = HAS_BIAS ? fmaf(st[ks][qt][r], kScale2, uu[r] * flagq[qt]) : st[ks][qt][r] * kScale2;
-          st[ks][qt][r] = fexp2<T>(e) * dp[ks][qt][r];
-        }
-      }
-    }
+    // leave the MFMA chains ready for p = exp2(c S' [+ bias]) and dS = p dP' (one subtraction per score less).
+    // The 64 keys of the tile go through in two halves of 32 (= the two contraction macro steps of dQ += dS K): 16 instead of 32
+    // score / dP accumulator tiles live at a time.
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
+      f32x4 st[2][2], dp[2][2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+          Frag<T> fk, fv;
+          tile_rowfrag<T>(fk, Ks, (2 * ms + k2) * 16 + li, s);
+          tile_rowfrag<T>(fv, Vs, (2 * ms + k2) * 16 + li, s);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            st[k2][qt] = mma16(fk, fq[qt][s], s == 0 ? sinit[qt] : st[k2][qt]);
+            dp[k2][qt] = mma16(fv, fdo[qt][s], s == 0 ? dinit[qt] : dp[k2][qt]);
+          }
+        }
+      // (keys beyond N need no masking here: their K rows are zero in the LDS image, so whatever dS holds for them adds
+      //  nothing to dQ = dS K; p and dP' stay finite - S' = -lse, dP' = -delta)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        f32x4 uu = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (HAS_BIAS) uu = *reinterpret_cast<const f32x4*>(us + (2 * ms + k2) * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            float e;
+            if constexpr (PRESCALE) e = HAS_BIAS ? fmaf(uu[r], flagq[qt], st[k2][qt][r]) : st[k2][qt][r];
+            else e = HAS_BIAS ? fmaf(st[k2][qt][r], kScale2, uu[r] * flagq[qt]) : st[k2][qt][r] * kScale2;
+            st[k2][qt][r] = fexp2<T>(e) * dp[k2][qt][r];
+          }
+        }
+      }
       Frag<T> pa[2];
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) acc_to_frag<T>(pa[qt], st[2 * ms][qt], st[2 * ms + 1][qt]);
+      for (int qt = 0; qt < 2; ++qt) acc_to_frag<T>(pa[qt], st[0][qt], st[1][qt]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         Frag<T> fk;
