@@ -196,6 +196,37 @@ class OracleSegmentor(nn.Module):
         self.train(was)
         return res
 
+    def slide_test(self, img, img_shape, ori_shape, crop_size, stride, flip=None, ema=False):
+        """encoder_decoder.py:1068-1116 (slide_inference) + 1193-1216: overlapping crop_size windows at `stride`, the last one
+        of a row / column shifted back inside the image; window logits summed (F.pad to the image = add inside the window),
+        divided by the cover count, then ops.whole_inference_post.  -> (prob, label)"""
+        bb, hd = (self.backbone_ema, self.decode_head_ema) if ema else (self.backbone, self.decode_head)
+        was = self.training
+        self.eval()
+        with torch.no_grad():
+            h_stride, w_stride = stride
+            h_crop, w_crop = crop_size
+            bs, _, h_img, w_img = img.shape
+            h_grids = max(h_img - h_crop + h_stride - 1, 0) // h_stride + 1
+            w_grids = max(w_img - w_crop + w_stride - 1, 0) // w_stride + 1
+            preds = img.new_zeros((bs, hd.num_classes, h_img, w_img))
+            count = img.new_zeros((bs, 1, h_img, w_img))
+            for h_idx in range(h_grids):
+                for w_idx in range(w_grids):
+                    y1, x1 = h_idx * h_stride, w_idx * w_stride
+                    y2, x2 = min(y1 + h_crop, h_img), min(x1 + w_crop, w_img)
+                    y1, x1 = max(y2 - h_crop, 0), max(x2 - w_crop, 0)
+                    crop = img[:, :, y1:y2, x1:x2]
+                    out = hd(bb(crop))
+                    if tuple(out.shape[2:]) != tuple(crop.shape[2:]):
+                        out = O.resize(out, crop.shape[2:], False)
+                    preds += F.pad(out, (int(x1), int(w_img - x2), int(y1), int(h_img - y2)))
+                    count[:, :, y1:y2, x1:x2] += 1
+            assert (count == 0).sum() == 0
+            res = O.whole_inference_post(preds / count, img_shape, ori_shape, flip, False)
+        self.train(was)
+        return res
+
     def compute_pseudo_loss(self, feat, tinfo, patchmix_n=0, perms=None):
         """encoder_decoder.py:906-954 (NCR: mode 'unsup_only')"""
         pred = self.decode_head(feat, patchmix_n, perms)

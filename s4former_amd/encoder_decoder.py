@@ -390,7 +390,34 @@ class EncoderDecoder(BaseSegmentor):
         return seg_logit
 
     def slide_inference(self, img, img_meta, rescale):
-        raise S4FError("test_cfg.mode='slide' is not built: the SETR configs evaluate with mode='whole' (configs/setr/*:251)")
+        """encoder_decoder.py:1068-1116: overlapping windows of test_cfg.crop_size at test_cfg.stride (the last window of a
+        row / column is shifted back inside the image), the windows' logits summed where they land and divided by the
+        cover count.  Every window goes through the HIP forward; the sum / count / crop bookkeeping is the reference's
+        torch arithmetic (adding the zero-padded window logits = adding them inside the window)."""
+        tc = self.test_cfg
+        get = tc.get if isinstance(tc, dict) else (lambda k: getattr(tc, k))
+        h_stride, w_stride = get('stride')
+        h_crop, w_crop = get('crop_size')
+        batch_size, _, h_img, w_img = img.size()
+        h_grids = max(h_img - h_crop + h_stride - 1, 0) // h_stride + 1
+        w_grids = max(w_img - w_crop + w_stride - 1, 0) // w_stride + 1
+        preds = img.new_zeros((batch_size, self.num_classes, h_img, w_img))
+        count_mat = img.new_zeros((batch_size, 1, h_img, w_img))
+        for h_idx in range(h_grids):
+            for w_idx in range(w_grids):
+                y1, x1 = h_idx * h_stride, w_idx * w_stride
+                y2, x2 = min(y1 + h_crop, h_img), min(x1 + w_crop, w_img)
+                y1, x1 = max(y2 - h_crop, 0), max(x2 - w_crop, 0)
+                crop_img = img[:, :, y1:y2, x1:x2].contiguous()
+                logit = self.encode_decode_ema(crop_img, img_meta) if self.ema_test else self.encode_decode(crop_img, img_meta)
+                preds[:, :, y1:y2, x1:x2] += logit
+                count_mat[:, :, y1:y2, x1:x2] += 1
+        assert (count_mat == 0).sum() == 0
+        preds = preds / count_mat
+        if rescale:
+            resize_shape = img_meta[0]['img_shape'][:2]          # remove padding area: read only this window
+            preds = K.resize_bilinear(preds.contiguous(), img_meta[0]['ori_shape'][:2], self.align_corners, window=resize_shape)
+        return preds
 
     def inference(self, img, img_meta, rescale, return_labels=False):
         """encoder_decoder.py:1174-1203 -> softmax probabilities [B, C, H, W], flipped back when the test image was flipped

@@ -223,3 +223,12 @@ SAMPLER_CASES = {
     'ratio_1_3': dict(cumulative_sizes=[20, 100], sample_ratio=[1, 3], samples_per_gpu=8, num_replicas=2, max_iter_size=12,
                       epochs=[5]),
 }
+
+
+# ------------------------------------------------------------------------------------------------ sliding-window evaluation
+SLIDE_CASE = dict(crop=(64, 64), stride=(32, 48), img_shape=(90, 100), ori_shape=(120, 131), seed_w=1999, gain=5.0, seed_x=91)
+
+
+def slide_input():
+    g = torch.Generator().manual_seed(SLIDE_CASE['seed_x'])
+    return torch.randn(2, 3, 96, 112, generator=g).clamp_(-2.2, 2.7)

@@ -19,3 +19,24 @@ def test_oracle_metrics_match_the_reference(name):
     assert np.array_equal(np.stack([t.numpy() for t in tot]), GOLD[f'{name}_areas'])      # pixel counts: exact
     for k in ('aAcc', 'IoU', 'Acc'):
         np.testing.assert_allclose(ret[k], GOLD[f'{name}_{k}'], rtol=1e-12, equal_nan=True)
+
+
+def test_oracle_slide_inference_matches_the_reference_golden():
+    """test_cfg.mode='slide' (encoder_decoder.py:1068-1116): the oracle's restatement against what the reference's own
+    slide_inference / inference returned (tests/golden/make_golden_slide.py; its ema_test path, which runs as written)"""
+    import json
+
+    import torch
+
+    from oracle import model as OM
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'eval_slide.npz'))
+    S = C.SLIDE_CASE
+    imgs = C.slide_input()
+    assert C.sha(imgs) == json.loads(str(z['meta']))['input_sha']
+    cfg = C.tiny_model_cfg(unsup_weight=1.0)
+    orc = OM.oracle_from_cfg(cfg)
+    C.load_filled(orc, S['seed_w'], S['gain'])
+    for tag, flip in (('plain', None), ('flip', 'horizontal')):
+        prob, lab = orc.slide_test(imgs, S['img_shape'], S['ori_shape'], S['crop'], S['stride'], flip, ema=True)
+        assert np.array_equal(lab.numpy().astype(np.uint8), z[f'{tag}_label'])
+        assert float((prob.max(1).values - torch.from_numpy(z[f'{tag}_pmax'])).abs().max()) <= 1e-6

@@ -128,3 +128,45 @@ def test_whole_image_inference_vs_oracle(dtype, ema):
         assert abs(float(a) - float(b)) < (2e-3 if dtype == 'fp32' else 0.2)
     finally:
         S.set_compute_dtype('fp32')
+
+
+@pytest.mark.parametrize('dtype,ema', [('fp32', False), ('fp32', True), ('bf16', False)])
+def test_slide_inference_vs_oracle(dtype, ema):
+    """test_cfg.mode='slide' (encoder_decoder.py:1068-1116): 64 x 64 windows at stride (32, 48) over a 96 x 112 input - 2 x 2
+    windows, the last of each row / column shifted back inside the image, overlaps averaged - padded area removed, rescaled"""
+    S.set_compute_dtype(dtype)
+    try:
+        cfg = C.tiny_model_cfg(unsup_weight=1.0, ema_test=ema)
+        cfg['test_cfg'] = dict(mode='slide', crop_size=(64, 64), stride=(32, 48))
+        model = S.build_segmentor(cfg)
+        vals = C.load_filled(model, C.SLIDE_CASE['seed_w'], C.SLIDE_CASE['gain'])
+        model.cuda().eval()
+        ocfg = dict(cfg)
+        ocfg.pop('ema_test')
+        orc = OM.oracle_from_cfg(ocfg)
+        orc.load_state_dict(vals, strict=True)
+        imgs = C.slide_input()
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'eval_slide.npz'))
+        for flip in (None, 'horizontal'):
+            meta = [dict(img_shape=(90, 100, 3), ori_shape=(120, 131, 3), pad_shape=(96, 112, 3), flip=flip is not None,
+                         flip_direction=flip or 'horizontal') for _ in range(2)]
+            out = model(img=[imgs.cuda()], img_metas=[meta], return_loss=False)
+            prob_ref, lab_ref = orc.slide_test(imgs, (90, 100), (120, 131), (64, 64), (32, 48), flip, ema=ema)
+            assert len(out) == 2 and out[0].shape == (120, 131)
+            got = np.stack(out)
+            prob = model.inference(imgs.cuda(), meta, True).cpu()
+            if dtype == 'fp32':
+                top2 = prob_ref.topk(2, dim=1).values
+                near = ((top2[:, 0] - top2[:, 1]) < 1e-4).numpy()
+                assert not ((got != lab_ref.numpy()) & ~near).any()
+                assert float((prob - prob_ref).abs().max()) < 1e-4
+                if ema:      # the reference's own slide_inference output (its ema_test path runs as written)
+                    tag = 'flip' if flip else 'plain'
+                    bad = (got != gold[f'{tag}_label']) & (gold[f'{tag}_margin'] >= 1e-4)
+                    assert not bad.any(), f'{int(bad.sum())} labels differ from the reference outside near-ties'
+                    assert float(np.abs(prob.max(1).values.numpy() - gold[f'{tag}_pmax']).max()) < 1e-4
+            else:
+                assert (got != lab_ref.numpy()).mean() < 0.1
+                assert float((prob - prob_ref).abs().max()) < 5e-2
+    finally:
+        S.set_compute_dtype('fp32')
