@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""In-step check of the GEMM variant table: the shipped choices were timed kernel by kernel; here one signature at a time is
+switched to an alternative variant and the WHOLE step is timed (bench.py as a child process with S4F_TUNE_CACHE=<temp table>),
+with the unmodified table re-run regularly to follow the box's drift.
+  python tools/exp/instep_tune.py <shard> <nshards> [workload]          (GPU box; ~20 s per run)"""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+TABLE = os.path.join(ROOT, 's4former_amd', 'tuned_gfx950.json')
+
+
+def run(table_path, workload):
+    env = dict(os.environ, S4F_TUNE_CACHE=table_path)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '24', '--warmup', '8', '--no-cpu-baseline',
+                        '--no-kernel-profile', '--workload', workload], env=env, capture_output=True, text=True, timeout=300)
+    for line in r.stdout.splitlines():
+        if line.startswith('{"metric"'):
+            return json.loads(line)['ms_per_step']
+    return None
+
+
+def main():
+    shard, nshards = int(sys.argv[1]), int(sys.argv[2])
+    workload = sys.argv[3] if len(sys.argv) > 3 else 'semi'
+    rows = 16400 if workload == 'semi' else None
+    table = json.load(open(TABLE))
+    cands = []
+    for k, v in table.items():
+        key = eval(k)
+        if len(key) < 14:
+            continue
+        a_mode, b_mode, M, N, K = key[:5]
+        atomic = key[9]
+        if atomic or a_mode not in (0, 2) or b_mode != 0:
+            continue
+        if workload == 'semi' and a_mode == 0 and M not in (16400, 8200):
+            continue
+        if workload == 'semi' and a_mode == 2 and key[7] and key[7][0] != 8:
+            continue
+        alts = [h for h in (2, 4, 8, 9, 10) if h != v[0]]
+        if N % 256:
+            alts = [h for h in alts if h not in (4, 10)]
+        if N % 192 or a_mode != 0:
+            alts = [h for h in alts if h not in (8, 9)]
+        for h in alts:
+            cands.append((k, v, h))
+    cands = cands[shard::nshards]
+    print(f'{len(cands)} candidates in shard {shard}/{nshards}', flush=True)
+    base = []
+    with tempfile.TemporaryDirectory() as td:
+        tp = os.path.join(td, 't.json')
+        for i, (k, v, h) in enumerate(cands):
+            if i % 6 == 0:
+                json.dump(table, open(tp, 'w'))
+                b = run(tp, workload)
+                base.append(b)
+                print(f'   baseline {b}', flush=True)
+            mod = dict(table)
+            mod[k] = [h, v[1]]
+            json.dump(mod, open(tp, 'w'))
+            ms = run(tp, workload)
+            key = eval(k)
+            d = None if (ms is None or base[-1] is None) else ms - base[-1]
+            print(f'{str(key[:5]):34s} act {key[8]} f32 {int(key[10])} t {int(key[11])} resid {int(key[12])}: {v[0]:2d} -> {h:2d}: {ms} ms '
+                  f'({"n/a" if d is None else f"{d:+.3f}"})', flush=True)
+
+
+if __name__ == '__main__':
+    main()
