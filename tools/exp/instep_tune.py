@@ -48,6 +48,18 @@ def main():
             alts = [h for h in alts if h not in (8, 9)]
         for h in alts:
             cands.append((k, v, h))
+    if os.environ.get('TUNE_ATOMIC'):          # split-K problems: neighbouring split factors instead of other variants
+        cands = []
+        for k, v in table.items():
+            key = eval(k)
+            if key[0] == 'wgrad_grouped':
+                if workload == 'semi' and key[1][2] != 16400:
+                    continue
+                cands += [(k, v, (v[0], s_)) for s_ in (1, 3, 4) if s_ != v[1]]
+            elif len(key) >= 14 and key[9]:
+                if workload == 'semi' and ((key[7] and key[7][0] != 8) or key[4] in (18440, 147456, 589824, 36864, 9216, 8200)):
+                    continue
+                cands += [(k, v, (v[0], s_)) for s_ in sorted({max(1, v[1] // 2), v[1] * 2, max(1, (v[1] * 3) // 4), (v[1] * 3) // 2}) if s_ != v[1]]
     cands = cands[shard::nshards]
     print(f'{len(cands)} candidates in shard {shard}/{nshards}', flush=True)
     base = []
@@ -60,11 +72,14 @@ def main():
                 base.append(b)
                 print(f'   baseline {b}', flush=True)
             mod = dict(table)
-            mod[k] = [h, v[1]]
+            mod[k] = list(h) if isinstance(h, tuple) else [h, v[1]]
             json.dump(mod, open(tp, 'w'))
             ms = run(tp, workload)
             key = eval(k)
             d = None if (ms is None or base[-1] is None) else ms - base[-1]
+            if isinstance(h, tuple):
+                print(f'{str(key[:5])[:60]:60s}: {v} -> {list(h)}: {ms} ms ({"n/a" if d is None else f"{d:+.3f}"})', flush=True)
+                continue
             print(f'{str(key[:5]):34s} act {key[8]} f32 {int(key[10])} t {int(key[11])} resid {int(key[12])}: {v[0]:2d} -> {h:2d}: {ms} ms '
                   f'({"n/a" if d is None else f"{d:+.3f}"})', flush=True)
 
