@@ -39,6 +39,10 @@ def main():
             continue
         if workload == 'semi' and a_mode == 0 and M not in (16400, 8200):
             continue
+        if workload == 'sup' and a_mode == 0 and M != 8200:
+            continue
+        if workload == 'sup' and a_mode == 2 and key[7] and key[7][0] != 8:
+            continue
         if workload == 'semi' and a_mode == 2 and key[7] and key[7][0] != 8:
             continue
         alts = [h for h in (2, 4, 8, 9, 10) if h != v[0]]
