@@ -19,7 +19,8 @@ def run(table_path, workload):
                         '--no-kernel-profile', '--workload', workload], env=env, capture_output=True, text=True, timeout=300)
     for line in r.stdout.splitlines():
         if line.startswith('{"metric"'):
-            return json.loads(line)['ms_per_step']
+            d = json.loads(line)
+            return d['ms_per_step'] if abs(d['losses']['loss']) < 1e3 else None
     return None
 
 
@@ -40,6 +41,10 @@ def main():
         if workload == 'semi' and a_mode == 0 and M not in (16400, 8200):
             continue
         if workload == 'sup' and a_mode == 0 and M != 8200:
+            continue
+        if workload == 'semi768' and a_mode == 0 and M not in (18440, 9220):
+            continue
+        if workload == 'semi768' and a_mode == 2 and key[7] and key[7][0] != 4:
             continue
         if workload == 'sup' and a_mode == 2 and key[7] and key[7][0] != 8:
             continue
