@@ -176,9 +176,11 @@ def test_one_rank_rccl_group_runs_the_data_path(single, tmp_path):
     assert json.loads(str(got['meta']))['backend'] == 'nccl'
     n_grad, n_bn = (int(v) for v in got['issued'])
     assert n_grad >= 2 * 4 and n_bn >= 2 * 10, (n_grad, n_bn)       # per step: >= one range per encoder layer, >= one exchange per BN call
+    # (two processes: the fp32 atomics of the split-K sums differ in their last bits from run to run - the bounds of the
+    #  two-rank comparison above)
     for it in range(2):
-        assert np.allclose(got[f'it{it}_loss_vals'], ref[f'it{it}_loss_vals'], rtol=1e-6, atol=1e-7), it
-    assert np.allclose(got['state_abs_sum'], ref['state_abs_sum'], rtol=2e-6, atol=1e-7)
+        assert np.allclose(got[f'it{it}_loss_vals'], ref[f'it{it}_loss_vals'], rtol=1e-5, atol=1e-7), it
+    assert np.allclose(got['state_abs_sum'], ref['state_abs_sum'], rtol=2e-5, atol=1e-7)
     assert np.array_equal(got['nbt'], ref['nbt'])
 
 
