@@ -142,10 +142,11 @@ def setup_data_parallel(model, optimizer, device, reducer=None):
     build the arenas, make the replicas identical (broadcast of rank 0's student and teacher arenas), hook the gradient
     reducer into the per-range `range_done` notifications and, unless S4F_EAGER_SGD=0, the optimiser's eager per-range step.
 
-    N > 1 defaults are the plain ones: per-range all-reduce on a communication stream during backward, the SGD of a range
-    behind its all-reduce.  The measured-on-one-GPU-only variants stay opt-in until they have run on RCCL:
-    S4F_STREAM_LAYOUT=1 (first-use order of the streams, functional.lay_out_streams), S4F_AUX_LOCKSTEP=1 /
-    S4F_DECODE_LOCKSTEP=1 (heads advancing in lockstep, one SyncBN exchange per layer for all of them).
+    N > 1 defaults: per-range all-reduce during backward, the SGD of a range behind its all-reduce, and the first-use order
+    of the streams that puts the communication on the weight-gradient stream's hardware queue (functional.lay_out_streams;
+    S4F_STREAM_LAYOUT=0 turns it off).  Still opt-in, because they change the ORDER in which collectives are issued and no
+    run with peers exists yet: S4F_AUX_LOCKSTEP=1 / S4F_DECODE_LOCKSTEP=1 (heads advancing in lockstep, one SyncBN exchange
+    per layer for all of them; another -0.45 ms in the one-rank RCCL run).
     Returns the reducer; per step:  backward -> join_side_streams() -> reducer.reduce_(store.grad) -> reducer.wait() ->
     optimizer.step(grad_scale=reducer.grad_scale())."""
     reducer = reducer if reducer is not None else GradReducer()
@@ -157,7 +158,11 @@ def setup_data_parallel(model, optimizer, device, reducer=None):
     if model.teacher_store is not None:
         model.teacher_store.mark_dirty()
     reducer.attach(model.student_store)
-    if collectives_active() and os.environ.get('S4F_STREAM_LAYOUT', '0') == '1':
+    if collectives_active() and os.environ.get('S4F_STREAM_LAYOUT', '1') != '0' and torch.device(device).type == 'cuda':
+        # ON by default since round 2: measured through RCCL itself (one-rank group, tools/exp/rccl_world1.py) the step costs
+        # 33.95 ms with the streams bound to hardware queues in whatever order they are first used and 32.58 ms with this
+        # order (30.75 ms without any process group).  It changes which streams share a queue, never what runs or in which
+        # order the collectives are issued.
         from .functional import lay_out_streams
         reducer._stream = lay_out_streams(device)      # collectives + eager SGD issue from the weight-gradient stream
     if os.environ.get('S4F_EAGER_SGD', '1') != '0':

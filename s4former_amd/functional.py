@@ -52,8 +52,9 @@ def head_stream(device, name, priority=0):
 
 
 def lay_out_streams(device):
-    """OPT-IN (S4F_STREAM_LAYOUT=1; dist.setup_data_parallel): inferred on one-GPU boxes with a stand-in for RCCL's stream
-    (tools/exp/queue_map.py, tools/exp/rehearsal.py), never measured with real RCCL streams.
+    """The N > 1 default since round 2 (dist.setup_data_parallel; S4F_STREAM_LAYOUT=0 turns it off).  First inferred on one-GPU
+    boxes with a stand-in for RCCL's stream (tools/exp/queue_map.py, tools/exp/rehearsal.py), then measured through RCCL
+    itself with a one-rank process group (tools/exp/rccl_world1.py: 33.95 -> 32.58 ms per step); not yet with peers.
     N > 1 only, after the first collective (RCCL's stream has then been USED first).  The runtime has FOUR hardware
     queues; the default stream owns queue 1 and every other stream is bound at its first use, in the fixed pattern
     2 3 4 4 3 2 1 4 ... (tools/exp/queue_map.py); two streams on one queue serialise.  Wanted: the chain alone on queue 1,

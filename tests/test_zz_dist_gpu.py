@@ -110,12 +110,12 @@ VARIANTS = {
     'default': {},
     'no_eager_sgd': dict(S4F_EAGER_SGD='0'),
     'lockstep_heads': dict(S4F_AUX_LOCKSTEP='1', S4F_DECODE_LOCKSTEP='1'),
-    'stream_layout': dict(S4F_STREAM_LAYOUT='1'),
+    'no_stream_layout': dict(S4F_STREAM_LAYOUT='0'),
 }
 
 
 @pytest.mark.parametrize('variant,flags', [('default', 'pasa'), ('default', 'plain'), ('no_eager_sgd', 'pasa'),
-                                           ('lockstep_heads', 'pasa'), ('stream_layout', 'plain')])
+                                           ('lockstep_heads', 'pasa'), ('no_stream_layout', 'plain')])
 def test_two_ranks_equal_one_rank_on_the_concatenated_batch(variant, flags, single, tmp_path):
     d = str(tmp_path)
     port = 29600 + sorted(VARIANTS).index(variant) * 2 + (flags == 'plain')

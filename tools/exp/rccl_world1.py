@@ -38,14 +38,22 @@ if __name__ == '__main__':
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))
+    only = os.environ.get('RCCL1_ONLY', '')          # 'grad' | 'bn': force only one kind of exchange (cost attribution)
     D.collectives_active = lambda: True
     issue0 = D.GradReducer.issue
 
     def _issue(t):
         CALLS['grad'] += 1
         return issue0(t)
-    D.GradReducer.issue = staticmethod(_issue)
-    F_._Exchange.reduce = _reduce
+    if only != 'bn':
+        D.GradReducer.issue = staticmethod(_issue)
+    else:
+        class _Done:
+            def wait(self):
+                pass
+        D.GradReducer.issue = staticmethod(lambda t: _Done())
+    if only != 'grad':
+        F_._Exchange.reduce = _reduce
     sys.argv = [os.path.join(ROOT, 'bench.py')] + argv
     try:
         runpy.run_path(sys.argv[0], run_name='__main__')
