@@ -1648,6 +1648,14 @@ S4F_API int s4f_bn_relu_cls_fwd(const void* y, const float* scale, const float* 
   const size_t shm = 32 * (C * esz + 16) + 2 * C * sizeof(float);
   int grid = ceil_div(ceil_div(npix, 16), 4 * 4);
   if (grid > 2048) grid = 2048;
+  if (shm > 48 * 1024) {          // (C = 512 in fp32: 70 KB of dynamic LDS)
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)bn_relu_cls_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      hipFuncSetAttribute((const void*)bn_relu_cls_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr_set = true;
+    }
+  }
   if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_relu_cls_fwd_kernel<bf16_t>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)y, scale, shift, (const bf16_t*)seg_w, seg_b, logits, ld_logits, (bf16_t*)feat, (long)npix, C, ncls);
   else hipLaunchKernelGGL(bn_relu_cls_fwd_kernel<float>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const float*)y, scale, shift, (const float*)seg_w, seg_b, logits, ld_logits, (float*)feat, (long)npix, C, ncls);
   S4F_LAUNCH_CHECK();
