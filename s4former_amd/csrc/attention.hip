@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64 * NW, (QT == 4) ? 2 : ((NW == 8 && sizeof(T) == 
 }
 
 // ------------------------------------------------------------------------------------------ dQ
-// blocks per CU the dQ kernel is compiled for: 3 (<= 168 registers; the two-halves loop below needs 158 - 179)
+// blocks per CU the bf16 four-wave dQ kernel is compiled for: 3 (<= 168 registers; the two-halves loop below needs 158 - 179)
 #ifndef ATTN_DQ_MINB
 #define ATTN_DQ_MINB 3
 #endif
@@ -566,7 +566,7 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_fwd2_kernel(const AttnArgs a)
 }
 
 template <typename T, int NW, bool HAS_BIAS>
-__global__ __launch_bounds__(64 * NW, ATTN_DQ_MINB) void attn_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && NW == 4) ? ATTN_DQ_MINB : 1) void attn_dq_kernel(const AttnArgs a) {
   using C = ACfg<T>;
   constexpr bool PRESCALE = sizeof(T) == 2;
   constexpr int NT = 64 * NW;
