@@ -112,3 +112,29 @@ def test_strong_augmentation_decisions_follow_the_reference_rng_order():
         got = tok.reshape(-1, 8)[torch.from_numpy(fwd).long()].reshape(3, 17, 8)
         assert torch.equal(got[:, 1:], O.repatchmix_tokens(tok[:, 1:], p2, 2)) and torch.equal(got[:, 0], tok[:, 0])
         assert torch.equal(got.reshape(-1, 8)[torch.from_numpy(bwd).long()].reshape(3, 17, 8), tok)
+
+
+def test_shipped_tuning_table_is_well_formed():
+    """s4former_amd/tuned_gfx950.json: every key is a GEMM signature the host code can produce, every value a (tile variant,
+    split-K) pair the library accepts - a malformed entry would only show up as a slow or failing launch on the GPU box"""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 's4former_amd', 'tuned_gfx950.json')
+    table = json.load(open(path))
+    assert len(table) >= 60
+    for k, v in table.items():
+        key = eval(k, {'__builtins__': {}}, {})
+        assert isinstance(key, tuple) and isinstance(v, list) and len(v) == 2, k
+        hint, sk = v
+        assert hint in (1, 2, 3, 4, 8, 9, 10) and isinstance(sk, int) and sk >= 1, (k, v)
+        if key[0] == 'wgrad_grouped':
+            assert 2 <= len(key) <= 5 and all(len(t) == 3 for t in key[1:]), k
+            continue
+        assert len(key) == 14, k
+        a_mode, b_mode, M, N, K = key[:5]
+        assert a_mode in (0, 1, 2) and b_mode in (0, 1, 2, 3, 4) and min(M, N, K) > 0, k
+        atomic = key[9]
+        assert atomic or sk == 1, (k, v)                     # split-K needs the atomic fp32 output
+        if hint in (3, 4, 10):
+            assert N % 256 == 0 or a_mode == 1, (k, v)       # 256-wide tiles
+        if hint in (8, 9):
+            assert N % 192 == 0, (k, v)
