@@ -62,13 +62,16 @@ def main():
         for k, v in table.items():
             key = eval(k)
             if key[0] == 'wgrad_grouped':
-                if (workload == 'semi' and key[1][2] != 16400) or (workload == 'semi768' and key[1][2] != 18440):
+                if (workload == 'semi' and key[1][2] != 16400) or (workload == 'semi768' and key[1][2] != 18440) or \
+                        (workload == 'sup' and key[1][2] != 8200):
                     continue
                 cands += [(k, v, (v[0], s_)) for s_ in (1, 3, 4) if s_ != v[1]]
             elif len(key) >= 14 and key[9]:
                 if workload == 'semi' and ((key[7] and key[7][0] != 8) or key[4] in (18440, 147456, 589824, 36864, 9216, 8200)):
                     continue
                 if workload == 'semi768' and not ((key[7] and key[7][0] == 4) or key[4] in (18440, 147456, 589824)):
+                    continue
+                if workload == 'sup' and not (key[4] == 8200 or (key[0], key[1]) == (2, 0)):
                     continue
                 cands += [(k, v, (v[0], s_)) for s_ in sorted({max(1, v[1] // 2), v[1] * 2, max(1, (v[1] * 3) // 4), (v[1] * 3) // 2}) if s_ != v[1]]
     cands = cands[shard::nshards]
