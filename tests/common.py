@@ -229,6 +229,9 @@ SAMPLER_CASES = {
 SLIDE_CASE = dict(crop=(64, 64), stride=(32, 48), img_shape=(90, 100), ori_shape=(120, 131), seed_w=1999, gain=5.0, seed_x=91)
 
 
+WHOLE_CASE = dict(img_shape=(60, 56), ori_shape=(83, 71), seed_x=77)      # with SLIDE_CASE's weights
+
+
 def slide_input():
     g = torch.Generator().manual_seed(SLIDE_CASE['seed_x'])
     return torch.randn(2, 3, 96, 112, generator=g).clamp_(-2.2, 2.7)

@@ -40,3 +40,20 @@ def test_oracle_slide_inference_matches_the_reference_golden():
         prob, lab = orc.slide_test(imgs, S['img_shape'], S['ori_shape'], S['crop'], S['stride'], flip, ema=True)
         assert np.array_equal(lab.numpy().astype(np.uint8), z[f'{tag}_label'])
         assert float((prob.max(1).values - torch.from_numpy(z[f'{tag}_pmax'])).abs().max()) <= 1e-6
+
+
+def test_oracle_whole_inference_matches_the_reference_golden():
+    """test_cfg.mode='whole' (encoder_decoder.py:1118-1147, 1174-1216): the oracle's simple_test against the reference's own
+    whole_inference / inference on its ema_test path (which runs as written; the non-EMA path raises - Q8)"""
+    import torch
+
+    from oracle import model as OM
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'eval_slide.npz'))
+    S, W = C.SLIDE_CASE, C.WHOLE_CASE
+    imgs, _, _ = C.make_batch(W['seed_x'], 2, 0)
+    orc = OM.oracle_from_cfg(C.tiny_model_cfg(unsup_weight=1.0))
+    C.load_filled(orc, S['seed_w'], S['gain'])
+    for tag, flip in (('whole_plain', None), ('whole_flip', 'horizontal')):
+        prob, lab = orc.simple_test(imgs, W['img_shape'], W['ori_shape'], flip, ema=True)
+        assert np.array_equal(lab.numpy().astype(np.uint8), z[f'{tag}_label'])
+        assert float((prob.max(1).values - torch.from_numpy(z[f'{tag}_pmax'])).abs().max()) <= 1e-6

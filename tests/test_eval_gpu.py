@@ -106,6 +106,12 @@ def test_whole_image_inference_vs_oracle(dtype, ema):
                 assert (got != lab_ref.numpy()).mean() < 0.1, 'bf16 perf mode: at least 90 % of the labels agree'
             prob = model.inference(imgs.cuda(), meta, True).cpu()
             assert float((prob - prob_ref).abs().max()) < (1e-4 if dtype == 'fp32' else 5e-2)
+            if dtype == 'fp32' and ema:      # the reference's OWN whole_inference output (its ema_test path runs as written)
+                gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'eval_slide.npz'))
+                tag = 'whole_flip' if flip else 'whole_plain'
+                bad = (got != gold[f'{tag}_label']) & (gold[f'{tag}_margin'] >= 1e-4)
+                assert not bad.any(), f'{int(bad.sum())} labels differ from the reference outside near-ties'
+                assert float(np.abs(prob.max(1).values.numpy() - gold[f'{tag}_pmax']).max()) < 1e-4
             results += out
             refs += list(lab_ref.numpy())
         # test-time augmentation: mean of the two probability maps
