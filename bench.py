@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--timeline', default='', help='write the HIP-event timeline of the profiled step (no tracer attached) to this JSON file')
     ap.add_argument('--mask-ratio', type=float, default=0.5,
                     help='target fraction of confident teacher pixels: the randomly initialised teacher conv_seg is '
                          'rescaled (bisection, untimed) so that the pseudo-label path is not degenerate (SURVEY §7)')
@@ -259,6 +260,9 @@ def main():
             step(it)
             it += 1
         summ = prof.summary()
+        if args.timeline:
+            with open(args.timeline, 'w') as f:
+                json.dump([(n, list(t) if t is not None else None, st, round(t0_, 4), round(d_, 4)) for n, t, st, t0_, d_ in prof.timeline()], f)
         fam = {}
         for (name, tag), d in summ.items():
             is_gemm = name in ('s4f_gemm', 's4f_gemm_grouped') and tag is not None

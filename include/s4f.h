@@ -8,7 +8,10 @@
  *   - return value 0 = ok, < 0 = error; the message is in s4f_last_error() (thread-local);
  *   - `dtype` selects the operand type T of matrix operands / activations: S4F_F32 (parity mode: exact fp32
  *     MFMA chain) or S4F_BF16 (perf mode: bf16 operands, fp32 accumulate).  Statistics, losses, master
- *     weights, gradients of parameters and the residual stream are always fp32;
+ *     weights and gradients of parameters are always fp32;
+ *   - `xdtype` (round 3) is the type X of the RESIDUAL STREAM (token tensors [B, T+1, C] between encoder layers and their
+ *     gradients, vit.py:113-127): S4F_F32, or S4F_BF16 in bf16 mode (every residual add is then rounded to bf16 once
+ *     more; the sums inside LayerNorm / the GEMM epilogues stay fp32);
  *   - re-entrant, no global mutable state, safe from several threads on different streams.
  */
 #ifndef S4F_H_
@@ -65,7 +68,7 @@ typedef struct s4f_gemm_desc {
   /* epilogue */
   float alpha;
   const float* bias;        /* [N] fp32 or NULL */
-  const float* resid;       /* fp32 [M, ldr] added to the result, or NULL */
+  const void* resid;        /* [M, ldr] added to the result, or NULL: fp32, or T if resid_t != 0 (see below) */
   int64_t ldr;
   float* out_f32;           /* optional fp32 output [M, ldo_f32] */
   int64_t ldo_f32;
@@ -91,7 +94,11 @@ typedef struct s4f_gemm_desc {
    * by a second pass over the tensor.  Only the 8-wave kernel's T-output path implements it (tile_hint 10, row-major
    * operands, N % 256 == 0, out_t only): s4f_gemm FAILS for any other combination rather than dropping it. */
   float* colsum;
-} s4f_gemm_desc;            /* 208 bytes (the kernels take the descriptor by value inside their argument struct) */
+  /* round 3: resid_t != 0 (bf16 mode only): `resid` points at T (bf16) values - the residual stream kept in the operand
+   * type; the sum leaves through out_t (out_f32 may be NULL).  Implemented by the coalesced epilogues (N % 8 == 0). */
+  int32_t resid_t;
+  int32_t reserved0;
+} s4f_gemm_desc;            /* 216 bytes (the kernels take the descriptor by value inside their argument struct) */
 
 int s4f_gemm(const s4f_gemm_desc* d, s4f_stream stream);
 
@@ -119,31 +126,33 @@ int s4f_transpose_many(const void* src, void* dst, const int64_t* items_dev, int
  * rows then line up with the token tensor [B, T+1, 768] (cls first, vit.py:486-487). */
 int s4f_im2col_patch16(const float* img, void* cols, int B, int H, int W, int pad_cls, int dtype, s4f_stream stream);
 
-/* tokens[b, 0, :] = cls + pos[0]  (vit.py:486-487,445). tokens fp32 [B, ntok, C]. */
-int s4f_cls_pos(const float* cls, const float* pos, float* tokens, int B, int ntok, int C, s4f_stream stream);
-/* backward of token assembly: dpos[t,:] += sum_b dtok[b,t,:]; dcls += sum_b dtok[b,0,:] (atomic into fp32) */
-int s4f_tokens_bwd(const float* dtok, float* dpos, float* dcls, int B, int ntok, int C, s4f_stream stream);
+/* tokens[b, 0, :] = cls + pos[0]  (vit.py:486-487,445). tokens X [B, ntok, C]. */
+int s4f_cls_pos(const float* cls, const float* pos, void* tokens, int B, int ntok, int C, int xdtype, s4f_stream stream);
+/* backward of token assembly: dpos[t,:] += sum_b dtok[b,t,:]; dcls += sum_b dtok[b,0,:] (atomic into fp32); dtok X */
+int s4f_tokens_bwd(const void* dtok, float* dpos, float* dcls, int B, int ntok, int C, int xdtype, s4f_stream stream);
 
 /* column sums (bias gradients): out[n] += sum_m X[m, n], X is T [M, ld]; rows with m % skip_period == 0 are
  * left out when skip_period > 0 (cls rows of a token tensor). */
 int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int skip_period, int dtype, s4f_stream stream);
 
-/* LayerNorm (vit.py:67-69,82-84; setr_up_head.py:49,103).  x fp32; output row r = (image b = r / rows_per_img,
+/* LayerNorm (vit.py:67-69,82-84; setr_up_head.py:49,103).  x X (xdtype); output row r = (image b = r / rows_per_img,
  * token t = r % rows_per_img) reads x + b * in_batch_stride + t * C  (in_batch_stride in elements; with
  * x pointing at token 1 and in_batch_stride = (T+1)*C this drops the cls token of each image: the head's
  * token->NCHW reshape, vit.py:555-562, is folded into this index map).  rows_per_img = rows, stride 0: plain.
  * y T [rows, C]; mean, rstd fp32 [rows]. C % 256 == 0, C <= 1024. */
-int s4f_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                      int rows, int C, int rows_per_img, int64_t in_batch_stride, float eps, int dtype,
+int s4f_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      int rows, int C, int rows_per_img, int64_t in_batch_stride, float eps, int dtype, int xdtype,
                       s4f_stream stream);
 /* dx (=|+=) LN backward of dy (T) ; dgamma/dbeta accumulated atomically (fp32).  dx, dx_t and dresid use the
- * same (in_batch_stride) row map as x.  dresid: optional fp32 gradient of the residual branch added to the
- * result.  dx fp32 output, dx_t optional T copy.  accumulate != 0: dx += (instead of =), dresid must be NULL.
+ * same (in_batch_stride) row map as x.  dresid: optional X gradient of the residual branch added to the
+ * result.  x, dresid, dx are X (xdtype); dx_t: optional T copy of an fp32 dx (NULL when X is bf16: dx is then T already).
+ * accumulate != 0: dx += (instead of =), dresid must be NULL.
  * dcolsum: optional fp32 [C], += column sums of the final dx (the bias gradient of the linear layer whose output this
  * gradient belongs to: vit.py:113-127, the proj / fc2 biases), accumulated atomically like dgamma / dbeta. */
-int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                      const float* dresid, float* dx, void* dx_t, float* dgamma, float* dbeta, float* dcolsum, int rows,
-                      int C, int rows_per_img, int64_t in_batch_stride, int accumulate, int dtype, s4f_stream stream);
+int s4f_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                      const void* dresid, void* dx, void* dx_t, float* dgamma, float* dbeta, float* dcolsum, int rows,
+                      int C, int rows_per_img, int64_t in_batch_stride, int accumulate, int dtype, int xdtype,
+                      s4f_stream stream);
 
 /* out = a + b (fp32), optional T copy of the sum */
 int s4f_add_f32(const float* a, const float* b, float* out, void* out_t, int64_t n, int dtype, s4f_stream stream);
@@ -249,8 +258,8 @@ int s4f_mix_images(const float* img, float* out, const int* box, const int* perm
                    s4f_stream stream);
 /* the same CutMix on the uint8 pseudo-labels [B, H, W] (labels are not shuffled) */
 int s4f_cutmix_labels(const uint8_t* labels, uint8_t* out, const int* box, int B, int H, int W, s4f_stream stream);
-/* out[r, :] = src[map[r], :]  (fp32 rows of C floats): the token un-shuffle of decode_head.py:186-212 and its adjoint */
-int s4f_gather_rows(const float* src, float* out, const int* map, int64_t rows, int C, s4f_stream stream);
+/* out[r, :] = src[map[r], :]  (rows of C values of type X): the token un-shuffle of decode_head.py:186-212 and its adjoint */
+int s4f_gather_rows(const void* src, void* out, const int* map, int64_t rows, int C, int xdtype, s4f_stream stream);
 
 /* ---- evaluation path -----------------------------------------------------------------------------------
  * mmseg.ops.resize (ops/wrappers.py:8-51) = F.interpolate(size, 'bilinear', align_corners) on fp32 NCHW planes.  The input

@@ -39,8 +39,9 @@ class GemmDesc(Structure):
         ('act', c_int32), ('atomic', c_int32),
         ('pos_period', c_int32), ('tile_hint', c_int32), ('pos', c_void_p),
         ('colsum', c_void_p),
+        ('resid_t', c_int32), ('reserved0', c_int32),
     ]
-assert ctypes.sizeof(GemmDesc) == 208, 'GemmDesc must mirror s4f_gemm_desc (include/s4f.h, static_assert in gemm.hip)'
+assert ctypes.sizeof(GemmDesc) == 216, 'GemmDesc must mirror s4f_gemm_desc (include/s4f.h, static_assert in gemm.hip)'
 
 
 _SIGS = {
@@ -50,12 +51,12 @@ _SIGS = {
     's4f_cast_back': [c_void_p, c_void_p, c_int64, c_int, c_void_p],
     's4f_transpose_many': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p],
     's4f_im2col_patch16': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    's4f_cls_pos': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    's4f_tokens_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    's4f_cls_pos': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_tokens_bwd': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     's4f_colsum': [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_int, c_void_p],
     's4f_layernorm_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64,
-                          c_float, c_int, c_void_p],
-    's4f_layernorm_bwd': [c_void_p] * 11 + [c_int, c_int, c_int, c_int64, c_int, c_int, c_void_p],
+                          c_float, c_int, c_int, c_void_p],
+    's4f_layernorm_bwd': [c_void_p] * 11 + [c_int, c_int, c_int, c_int64, c_int, c_int, c_int, c_void_p],
     's4f_add_f32': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     's4f_attention_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
                           c_void_p],
@@ -81,7 +82,7 @@ _SIGS = {
                     c_void_p],
     's4f_mix_images': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     's4f_cutmix_labels': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
-    's4f_gather_rows': [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
+    's4f_gather_rows': [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
     's4f_resize_bilinear_nchw': [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int, c_void_p],
     's4f_softmax_argmax_nchw': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     's4f_confusion_counts': [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p],
@@ -129,11 +130,21 @@ class CallProfiler:
 
     def __init__(self):
         self.entries = []
+        self.entries_raw = []
+        self.base = None
 
     def __enter__(self):
         global _prof
         self._prev, _prof = _prof, self
+        self.base = torch.cuda.Event(enable_timing=True)
+        self.base.record()
         return self
+
+    def timeline(self):
+        """[(name, tag, raw stream, start ms after __enter__, duration ms)] in issue order, after a device synchronise: the
+        GPU-side schedule of the profiled region WITHOUT a tracer attached (tools/event_timeline.py)"""
+        torch.cuda.synchronize()
+        return [(name, tag, st, self.base.elapsed_time(e0), e0.elapsed_time(e1)) for name, tag, e0, e1, st in self.entries_raw]
 
     def __exit__(self, *exc):
         global _prof
@@ -144,7 +155,7 @@ class CallProfiler:
         """{(name, tag): dict(calls, ms)} after a device synchronise"""
         torch.cuda.synchronize()
         out = {}
-        for name, tag, e0, e1 in self.entries:
+        for name, tag, e0, e1 in self.entries:   # (entries_raw carries the stream as a fifth field)
             d = out.setdefault((name, tag), dict(calls=0, ms=0.0))
             d['calls'] += 1
             d['ms'] += e0.elapsed_time(e1)
@@ -160,6 +171,7 @@ def call(name, *args, tag=None):
         rc = getattr(lib, name)(*args)
         e1.record()
         _prof.entries.append((name, tag, e0, e1))
+        _prof.entries_raw.append((name, tag, e0, e1, stream()))
     else:
         rc = getattr(lib, name)(*args)
     if rc != 0:

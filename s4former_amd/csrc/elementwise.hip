@@ -72,22 +72,24 @@ __global__ void im2col16_kernel(const float* __restrict__ img, T* __restrict__ c
   }
 }
 
-__global__ void cls_pos_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ tok,
+template <typename X>
+__global__ void cls_pos_kernel(const float* __restrict__ cls, const float* __restrict__ pos, X* __restrict__ tok,
                                int B, int ntok, int C) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   const int b = i / C, c = i % C;
-  tok[(long)b * ntok * C + c] = cls[c] + pos[c];
+  tok[(long)b * ntok * C + c] = (X)(cls[c] + pos[c]);
 }
 
 // dpos[t, c] += sum_b dtok[b, t, c]; dcls[c] += sum_b dtok[b, 0, c]
-__global__ void tokens_bwd_kernel(const float* __restrict__ dtok, float* __restrict__ dpos, float* __restrict__ dcls,
+template <typename X>
+__global__ void tokens_bwd_kernel(const X* __restrict__ dtok, float* __restrict__ dpos, float* __restrict__ dcls,
                                   int B, int ntok, int C) {
   const long total = (long)ntok * C;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dtok[(long)b * total + i];
+    for (int b = 0; b < B; ++b) s += (float)dtok[(long)b * total + i];
     atomicAdd(dpos + i, s);
     if (i < C) atomicAdd(dcls + i, s);
   }
@@ -143,8 +145,23 @@ __device__ __forceinline__ long ln_in_off(int r, int rows_per_img, long bstride,
   return (long)b * bstride + (long)(r - b * rows_per_img) * C;
 }
 
-template <typename T, int NV>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+  const bf16x4 b = *reinterpret_cast<const bf16x4*>(p);
+  return f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+  bf16x4 b;
+  b[0] = (bf16_t)v[0]; b[1] = (bf16_t)v[1]; b[2] = (bf16_t)v[2]; b[3] = (bf16_t)v[3];
+  *reinterpret_cast<bf16x4*>(p) = b;
+}
+
+// X = type of the residual stream (fp32; bf16 in perf mode since round 3), T = type of the normalised output
+template <typename T, typename X, int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const X* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows,
                                                      int rows_per_img, long bstride, float eps) {
@@ -159,12 +176,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     bt[v] = *reinterpret_cast<const f32x4*>(beta + v * 256 + lane * 4);
   }
   for (int r = wave_global; r < rows; r += nwaves) {
-    const float* xr = x + ln_in_off(r, rows_per_img, bstride, C);
+    const X* xr = x + ln_in_off(r, rows_per_img, bstride, C);
     f32x4 xv[NV];
     float s = 0.f;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-      xv[v] = *reinterpret_cast<const f32x4*>(xr + v * 256 + lane * 4);
+      xv[v] = load4<X>(xr + v * 256 + lane * 4);
       s += (xv[v][0] + xv[v][1]) + (xv[v][2] + xv[v][3]);
     }
     const float mu = wave_sum(s) * (1.f / C);
@@ -193,29 +210,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   }
 }
 
-template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
-template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
-  const bf16x4 b = *reinterpret_cast<const bf16x4*>(p);
-  return f32x4{(float)b[0], (float)b[1], (float)b[2], (float)b[3]};
-}
-template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
-template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
-  bf16x4 b;
-  b[0] = (bf16_t)v[0]; b[1] = (bf16_t)v[1]; b[2] = (bf16_t)v[2]; b[3] = (bf16_t)v[3];
-  *reinterpret_cast<bf16x4*>(p) = b;
-}
-
 // dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat)), dyg = dy * gamma ; dgamma += dy * xhat ; dbeta += dy
 // out = dx (+ dresid | + previous out);  dcolsum (optional) += column sums of out (= the bias gradient of the linear
 // layer that produced the residual branch this gradient flows into).
 // A wave owns two adjacent rows per iteration and issues every load of both (x, dy, dresid) before the first reduction.
-template <typename T, int NV>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const float* __restrict__ x,
+// X = type of the residual stream: x, dresid and dx (dx_t, the operand-typed copy of dx, only exists beside an fp32 dx)
+template <typename T, typename X, int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const X* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     const float* __restrict__ gamma, const float* __restrict__ dresid,
-                                                     float* __restrict__ dx, T* __restrict__ dx_t,
+                                                     const float* __restrict__ gamma, const X* __restrict__ dresid,
+                                                     X* __restrict__ dx, T* __restrict__ dx_t,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      float* __restrict__ dcolsum, int rows, int rows_per_img, long bstride,
                                                      int accumulate) {
@@ -245,12 +249,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
       const int r = live[u] ? r0 + u : r0;
       io[u] = ln_in_off(r, rows_per_img, bstride, C);
       mu[u] = mean[r]; rs[u] = rstd[r];
-      const float* prev = dresid ? dresid + io[u] : dx + io[u];
+      const X* prev = dresid ? dresid + io[u] : dx + io[u];
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
-        xh[u][v] = *reinterpret_cast<const f32x4*>(x + io[u] + v * 256 + lane * 4);
+        xh[u][v] = load4<X>(x + io[u] + v * 256 + lane * 4);
         dyv[u][v] = load4<T>(dy + (long)r * C + v * 256 + lane * 4);
-        if (has_prev) pv[u][v] = *reinterpret_cast<const f32x4*>(prev + v * 256 + lane * 4);
+        if (has_prev) pv[u][v] = load4<X>(prev + v * 256 + lane * 4);
         else pv[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
@@ -287,8 +291,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
         for (int e = 0; e < 4; ++e) o[e] = rs[u] * (dyv[u][v][e] * gm[v][e] - s1[u] - xh[u][v][e] * s2[u]);
         o += pv[u][v];
         dc[v] += o;
-        *reinterpret_cast<f32x4*>(dx + io[u] + v * 256 + lane * 4) = o;
-        if (dx_t) store4<T>(dx_t + io[u] + v * 256 + lane * 4, o);
+        store4<X>(dx + io[u] + v * 256 + lane * 4, o);
+        if constexpr (sizeof(X) == 4) {
+          if (dx_t) store4<T>(dx_t + io[u] + v * 256 + lane * 4, o);
+        }
       }
     }
   }
@@ -420,16 +426,15 @@ __global__ __launch_bounds__(256) void cutmix_labels_kernel(const uint8_t* __res
   }
 }
 
-// out row r = src row map[r] (rows of C floats; C % 4 == 0): the token un-shuffle of decode_head.py:186-212 and its adjoint
-__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, float* __restrict__ out,
-                                                          const int* __restrict__ map, long rows, int C) {
-  const int c4 = C / 4;
+// out row r = src row map[r] (rows of c4 16-byte chunks): the token un-shuffle of decode_head.py:186-212 and its adjoint
+__global__ __launch_bounds__(256) void gather_rows_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ out,
+                                                          const int* __restrict__ map, long rows, int c4) {
   const long total = rows * c4;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
     const long r = i / c4;
-    const int c = (int)(i - r * c4) * 4;
-    *reinterpret_cast<f32x4*>(out + r * C + c) = *reinterpret_cast<const f32x4*>(src + (long)map[r] * C + c);
+    const int c = (int)(i - r * c4);
+    out[r * c4 + c] = src[(long)map[r] * c4 + c];
   }
 }
 
@@ -523,16 +528,20 @@ S4F_API int s4f_im2col_patch16(const float* img, void* cols, int B, int H, int W
   return 0;
 }
 
-S4F_API int s4f_cls_pos(const float* cls, const float* pos, float* tokens, int B, int ntok, int C, s4f_stream stream) {
+S4F_API int s4f_cls_pos(const float* cls, const float* pos, void* tokens, int B, int ntok, int C, int xdtype, s4f_stream stream) {
   S4F_CHECK(cls && pos && tokens && B > 0 && ntok > 0 && C > 0, "s4f_cls_pos: bad args");
-  hipLaunchKernelGGL(cls_pos_kernel, dim3(ceil_div((long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, cls, pos, tokens, B, ntok, C);
+  S4F_CHECK(xdtype == S4F_F32 || xdtype == S4F_BF16, "s4f_cls_pos: bad xdtype");
+  if (xdtype == S4F_BF16) hipLaunchKernelGGL(cls_pos_kernel<bf16_t>, dim3(ceil_div((long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, cls, pos, (bf16_t*)tokens, B, ntok, C);
+  else hipLaunchKernelGGL(cls_pos_kernel<float>, dim3(ceil_div((long)B * C, 256)), dim3(256), 0, (hipStream_t)stream, cls, pos, (float*)tokens, B, ntok, C);
   S4F_LAUNCH_CHECK();
   return 0;
 }
 
-S4F_API int s4f_tokens_bwd(const float* dtok, float* dpos, float* dcls, int B, int ntok, int C, s4f_stream stream) {
+S4F_API int s4f_tokens_bwd(const void* dtok, float* dpos, float* dcls, int B, int ntok, int C, int xdtype, s4f_stream stream) {
   S4F_CHECK(dtok && dpos && dcls && B > 0 && ntok > 0 && C > 0, "s4f_tokens_bwd: bad args");
-  hipLaunchKernelGGL(tokens_bwd_kernel, dim3(grid_for((long)ntok * C, 256)), dim3(256), 0, (hipStream_t)stream, dtok, dpos, dcls, B, ntok, C);
+  S4F_CHECK(xdtype == S4F_F32 || xdtype == S4F_BF16, "s4f_tokens_bwd: bad xdtype");
+  if (xdtype == S4F_BF16) hipLaunchKernelGGL(tokens_bwd_kernel<bf16_t>, dim3(grid_for((long)ntok * C, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dtok, dpos, dcls, B, ntok, C);
+  else hipLaunchKernelGGL(tokens_bwd_kernel<float>, dim3(grid_for((long)ntok * C, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)dtok, dpos, dcls, B, ntok, C);
   S4F_LAUNCH_CHECK();
   return 0;
 }
@@ -553,34 +562,37 @@ S4F_API int s4f_colsum(const void* X, int64_t ld, int M, int N, float* out, int 
   return 0;
 }
 
-#define LN_DISPATCH(KERNEL, TT, ...)                                                                              \
+#define LN_DISPATCH(KERNEL, TT, XX, ...)                                                                              \
   switch (C / 256) {                                                                                              \
-    case 1: hipLaunchKernelGGL((KERNEL<TT, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
-    case 2: hipLaunchKernelGGL((KERNEL<TT, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
-    case 3: hipLaunchKernelGGL((KERNEL<TT, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
-    default: hipLaunchKernelGGL((KERNEL<TT, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 1: hipLaunchKernelGGL((KERNEL<TT, XX, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 2: hipLaunchKernelGGL((KERNEL<TT, XX, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    case 3: hipLaunchKernelGGL((KERNEL<TT, XX, 3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
+    default: hipLaunchKernelGGL((KERNEL<TT, XX, 4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); break; \
   }
 
-S4F_API int s4f_layernorm_fwd(const float* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                              int rows, int C, int rows_per_img, int64_t in_batch_stride, float eps, int dtype,
+S4F_API int s4f_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                              int rows, int C, int rows_per_img, int64_t in_batch_stride, float eps, int dtype, int xdtype,
                               s4f_stream stream) {
   DT_CHECK("s4f_layernorm_fwd");
+  S4F_CHECK(xdtype == S4F_F32 || (xdtype == S4F_BF16 && dtype == S4F_BF16), "s4f_layernorm_fwd: xdtype must be fp32, or bf16 in bf16 mode");
   S4F_CHECK(x && gamma && beta && y && mean && rstd, "s4f_layernorm_fwd: null pointer");
   S4F_CHECK(rows > 0 && C % 256 == 0 && C >= 256 && C <= 1024, "s4f_layernorm_fwd: C=%d must be a multiple of 256, <= 1024", C);
   S4F_CHECK(rows_per_img > 0, "s4f_layernorm_fwd: rows_per_img must be > 0");
   const long bstride = (long)in_batch_stride;
   const int grid = grid_for(rows, 4);
-  if (dtype == S4F_BF16) { LN_DISPATCH(ln_fwd_kernel, bf16_t, x, gamma, beta, (bf16_t*)y, mean, rstd, rows, rows_per_img, bstride, eps) }
-  else { LN_DISPATCH(ln_fwd_kernel, float, x, gamma, beta, (float*)y, mean, rstd, rows, rows_per_img, bstride, eps) }
+  if (xdtype == S4F_BF16) { LN_DISPATCH(ln_fwd_kernel, bf16_t, bf16_t, (const bf16_t*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, rows_per_img, bstride, eps) }
+  else if (dtype == S4F_BF16) { LN_DISPATCH(ln_fwd_kernel, bf16_t, float, (const float*)x, gamma, beta, (bf16_t*)y, mean, rstd, rows, rows_per_img, bstride, eps) }
+  else { LN_DISPATCH(ln_fwd_kernel, float, float, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, rows_per_img, bstride, eps) }
   S4F_LAUNCH_CHECK();
   return 0;
 }
 
-S4F_API int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                              const float* dresid, float* dx, void* dx_t, float* dgamma, float* dbeta, float* dcolsum,
-                              int rows, int C, int rows_per_img, int64_t in_batch_stride, int accumulate, int dtype,
+S4F_API int s4f_layernorm_bwd(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                              const void* dresid, void* dx, void* dx_t, float* dgamma, float* dbeta, float* dcolsum,
+                              int rows, int C, int rows_per_img, int64_t in_batch_stride, int accumulate, int dtype, int xdtype,
                               s4f_stream stream) {
   DT_CHECK("s4f_layernorm_bwd");
+  S4F_CHECK(xdtype == S4F_F32 || (xdtype == S4F_BF16 && dtype == S4F_BF16 && !dx_t), "s4f_layernorm_bwd: xdtype must be fp32, or bf16 in bf16 mode without dx_t");
   S4F_CHECK(dy && x && mean && rstd && gamma && dx && dgamma && dbeta, "s4f_layernorm_bwd: null pointer");
   S4F_CHECK(rows > 0 && C % 256 == 0 && C >= 256 && C <= 1024, "s4f_layernorm_bwd: C=%d must be a multiple of 256, <= 1024", C);
   S4F_CHECK(!(accumulate && dresid), "s4f_layernorm_bwd: accumulate and dresid are exclusive");
@@ -588,8 +600,9 @@ S4F_API int s4f_layernorm_bwd(const void* dy, const float* x, const float* mean,
   const long bstride = (long)in_batch_stride;
   int grid = grid_for(rows, 16);   // 4 rows per wave: fewer atomics on dgamma/dbeta
   if (grid > 512) grid = 512;
-  if (dtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, (const bf16_t*)dy, x, mean, rstd, gamma, dresid, dx, (bf16_t*)dx_t, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
-  else { LN_DISPATCH(ln_bwd_kernel, float, (const float*)dy, x, mean, rstd, gamma, dresid, dx, (float*)dx_t, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
+  if (xdtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, bf16_t, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dresid, (bf16_t*)dx, (bf16_t*)nullptr, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
+  else if (dtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, float, (const bf16_t*)dy, (const float*)x, mean, rstd, gamma, (const float*)dresid, (float*)dx, (bf16_t*)dx_t, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
+  else { LN_DISPATCH(ln_bwd_kernel, float, float, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)dresid, (float*)dx, (float*)dx_t, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
   S4F_LAUNCH_CHECK();
   return 0;
 }
@@ -611,9 +624,12 @@ S4F_API int s4f_cutmix_labels(const uint8_t* labels, uint8_t* out, const int* bo
   return 0;
 }
 
-S4F_API int s4f_gather_rows(const float* src, float* out, const int* map, int64_t rows, int C, s4f_stream stream) {
-  S4F_CHECK(src && out && map && src != out && rows > 0 && C > 0 && C % 4 == 0, "s4f_gather_rows: bad args");
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, src, out, map, (long)rows, C);
+S4F_API int s4f_gather_rows(const void* src, void* out, const int* map, int64_t rows, int C, int xdtype, s4f_stream stream) {
+  S4F_CHECK(xdtype == S4F_F32 || xdtype == S4F_BF16, "s4f_gather_rows: bad xdtype");
+  const int c4 = xdtype == S4F_BF16 ? C / 8 : C / 4;      // 16-byte chunks per row
+  S4F_CHECK(src && out && map && src != out && rows > 0 && C > 0 && C % (xdtype == S4F_BF16 ? 8 : 4) == 0, "s4f_gather_rows: bad args");
+  S4F_CHECK(((uintptr_t)src % 16) == 0 && ((uintptr_t)out % 16) == 0, "s4f_gather_rows: 16-B alignment");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * c4, 256)), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)out, map, (long)rows, c4);
   S4F_LAUNCH_CHECK();
   return 0;
 }

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs args) {
         } else if (d.act == S4F_ACT_GELU_BWD) {
           v *= to_f32<T>(aux[(long)m * d.ld_aux + n]);
         }
-        if (d.resid && first_split) v += d.resid[orow * d.ldr + n];
+        if (d.resid && first_split) v += d.resid_t ? (float)reinterpret_cast<const bf16_t*>(d.resid)[orow * d.ldr + n] : reinterpret_cast<const float*>(d.resid)[orow * d.ldr + n];
         if (d.out_f32) {
           if (d.atomic) atomicAdd(d.out_f32 + orow * d.ldo_f32 + n, v);
           else d.out_f32[orow * d.ldo_f32 + n] = v;
@@ -322,7 +322,7 @@ int dispatch(const s4f_gemm_desc& d, hipStream_t st) {
 
 }  // namespace
 
-static_assert(sizeof(s4f_gemm_desc) == 208, "s4f_gemm_desc changed: update _lib.GemmDesc (ctypes mirror) with it");
+static_assert(sizeof(s4f_gemm_desc) == 216, "s4f_gemm_desc changed: update _lib.GemmDesc (ctypes mirror) with it");
 
 int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn);   // gemm2.hip
 int s4f_gemm5_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm5.hip

@@ -228,6 +228,11 @@ __device__ __forceinline__ void frag_k(Frag<bf16_t>& f, const char* img, int col
   f.v = cv.b;
 }
 
+// residual value at element offset `off`: fp32, or the operand type (bf16 residual stream, s4f_gemm_desc.resid_t)
+__device__ __forceinline__ float resid_at(const s4f_gemm_desc& d, long off) {
+  return d.resid_t ? (float)reinterpret_cast<const bf16_t*>(d.resid)[off] : reinterpret_cast<const float*>(d.resid)[off];
+}
+
 // epilogue of 4 consecutive rows (m..m+3) of one column n: bias, pos, GELU / GELU', residual, fp32 / atomic / bf16 out
 __device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, int m, int n, float bias, bool first_split) {
   bf16_t* out_t = reinterpret_cast<bf16_t*>(d.out_t);
@@ -246,7 +251,7 @@ __device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, i
     } else if (d.act == S4F_ACT_GELU_BWD) {
       v *= (float)aux[(long)m * d.ld_aux + n];
     }
-    if (d.resid && first_split) v += d.resid[(long)m * d.ldr + n];
+    if (d.resid && first_split) v += resid_at(d, (long)m * d.ldr + n);
     if (d.out_f32) {
       if (d.atomic) atomicAdd(d.out_f32 + (long)m * d.ldo_f32 + n, v);
       else d.out_f32[(long)m * d.ldo_f32 + n] = v;
@@ -282,7 +287,7 @@ __device__ __forceinline__ void epilogue_rows(const s4f_gemm_desc& d, const floa
           float v = tile[row * LDT + col] * d.alpha;
           if (first_split) {
             if (d.bias) v += d.bias[n0 + col];
-            if (d.resid) v += d.resid[(long)m * d.ldr + n0 + col];
+            if (d.resid) v += resid_at(d, (long)m * d.ldr + n0 + col);
           }
           atomicAdd(d.out_f32 + (long)m * d.ldo_f32 + n0 + col, v);
         }
@@ -328,10 +333,16 @@ __device__ __forceinline__ void epilogue_rows(const s4f_gemm_desc& d, const floa
           for (int e = 0; e < 8; ++e) v[e] *= (float)z[e];
         }
         if (d.resid && first_split) {
-          const float* rp = d.resid + (long)m * d.ldr + n;
-          const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+          if (d.resid_t) {
+            const bf16x8 rb = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(d.resid) + (long)m * d.ldr + n);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+            for (int e = 0; e < 8; ++e) v[e] += (float)rb[e];
+          } else {
+            const float* rp = reinterpret_cast<const float*>(d.resid) + (long)m * d.ldr + n;
+            const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+          }
         }
         if (d.out_f32) {
           float* op = d.out_f32 + (long)m * d.ldo_f32 + n;
@@ -533,7 +544,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& args, const int bx, c
   // costs one memory instruction per 64 elements: ~1000 store instructions per tile, the dominant cost at K = 768.
   const bool wide = (d.N % 8 == 0) && (n0 + BN <= d.N) && (!d.atomic || (BMODE != S4F_OP_K_CONV && d.act == S4F_ACT_NONE && !d.out_t && !d.pos)) &&
                     (!d.out_t || d.ldo_t % 8 == 0) && (!d.out_pre || d.ldo_pre % 8 == 0) && (!d.aux || d.ld_aux % 8 == 0) &&
-                    (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % 4 == 0);
+                    (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % (d.resid_t ? 8 : 4) == 0);
   if (wide) {
     constexpr int LDT = BN + 4;                    // fp32 row stride of the staging tile (pad: rows 4 apart -> other banks)
     float* tile = reinterpret_cast<float*>(smem);

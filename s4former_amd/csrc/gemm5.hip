@@ -316,12 +316,13 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
   const bool first_split = (bz == 0);
   const bool wide = (d.N % 8 == 0) && (n0 + 256 <= d.N) && (!d.atomic || (d.act == S4F_ACT_NONE && !d.out_t && !d.pos)) &&
                     (!d.out_t || d.ldo_t % 8 == 0) && (!d.out_pre || d.ldo_pre % 8 == 0) && (!d.aux || d.ld_aux % 8 == 0) &&
-                    (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % 4 == 0);
+                    (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % (d.resid_t ? 8 : 4) == 0);
   // bf16 outputs (bias only: qkv, the input gradients, conv fwd / dgrad; GELU with its derivative: fc1; times a gelu'
   // tensor: the fc2 input gradient): the tile is staged ONCE as bf16 by all eight waves together (135 KiB) and leaves in
   // 16-byte rows - one barrier pair instead of two, half the LDS bytes of the fp32 staging.  The activations are applied
   // in the read-out to the bf16-rounded pre-activation (one more rounding to 8 bits before an 8-bit output).
-  const bool plain_t = wide && d.out_t && !d.out_f32 && !d.resid && !d.pos && !d.atomic &&
+  // (round 3: a bf16 residual - resid_t - is added in the read-out: out = bf16(bf16(acc + bias) + resid), the proj / fc2 GEMMs)
+  const bool plain_t = wide && d.out_t && !d.out_f32 && (!d.resid || d.resid_t) && !d.pos && !d.atomic &&
                        (d.act == S4F_ACT_NONE ? !d.out_pre : true);
   if (plain_t) {
     constexpr int LDB = 256 + 8;                     // staged row = 528 B
@@ -329,6 +330,7 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
     bf16_t* out_t = reinterpret_cast<bf16_t*>(d.out_t);
     bf16_t* out_pre = reinterpret_cast<bf16_t*>(d.out_pre);
     const bf16_t* aux = reinterpret_cast<const bf16_t*>(d.aux);
+    const bf16_t* res_t = reinterpret_cast<const bf16_t*>(d.resid);
     static_for<4>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
       const int col = wc * 64 + j * 16 + li;
@@ -372,6 +374,10 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
         const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * (float)z[e]);
+      } else if (res_t) {
+        const bf16x8 rr = *reinterpret_cast<const bf16x8*>(res_t + (long)m * d.ldr + n);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)rr[e]);
       }
       *reinterpret_cast<bf16x8*>(out_t + (long)m * d.ldo_t + n) = v;
       if (d.colsum) {

@@ -271,7 +271,7 @@ __device__ __forceinline__ void g6_body(const GemmArgs& args, const int tm, cons
   // ------------------------------------------------------------------ epilogue: fp32 out / atomic partial sums
   const bool first_split = (bz == 0);
   const bool wide = (d.N % 8 == 0) && (n0 + 256 <= d.N) && !d.out_t && !d.pos && d.act == S4F_ACT_NONE &&
-                    (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % 4 == 0);
+                    (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % (d.resid_t ? 8 : 4) == 0);
   if (wide) {
     // two passes of 128 staged fp32 rows; in pass p EVERY wave stages rows 64 p .. 64 p + 63 of its 128-row half
     constexpr int LDT = 256 + 4;

@@ -17,6 +17,7 @@ import torch.distributed as dist
 from torch.autograd import Function
 
 from . import kernels as K
+from . import runtime
 from ._lib import BF16, F32, S4FError
 
 SKIP_MASKED_COPY = os.environ.get('S4F_SKIP_MASKED_COPY', '1') != '0'     # A/B switch of head_backward's s = 1 stages
@@ -157,6 +158,20 @@ def _T(code):
     return torch.bfloat16 if code == BF16 else torch.float32
 
 
+def _R(code):
+    """torch dtype of the residual stream (token tensors between the layers and their gradients): fp32 in parity mode, the
+    operand type in bf16 mode unless S4F_RESID=fp32 (runtime.residual_dtype)"""
+    return torch.bfloat16 if (code == BF16 and runtime.residual_dtype() == BF16) else torch.float32
+
+
+def _gemm_resid(A, W, M, N, Kd, code, bias, resid, out, **kw):
+    """out[M, N] = A W^T + bias + resid, out / resid in the residual-stream type"""
+    if out.dtype == torch.bfloat16:
+        K.gemm(A, W, M, N, Kd, Kd, Kd, code, bias=bias, resid=resid, ldr=N if resid is not None else 0, out_t=out, ldo_t=N, **kw)
+    else:
+        K.gemm(A, W, M, N, Kd, Kd, Kd, code, bias=bias, resid=resid, ldr=N if resid is not None else 0, out_f32=out, ldo_f32=N, **kw)
+
+
 class _ZeroPool:
     """The step needs ~60 small zero-initialised fp32 accumulators (BN sums, loss sums, column sums).  One buffer,
     re-zeroed with ONE kernel at the start of forward_train, hands out slices instead of ~60 fill launches.  A slice is
@@ -257,10 +272,9 @@ class PatchEmbedFn(Function):
             raise S4FError(f'pos_embed has {pos.shape[1]} tokens, input needs {ntok} (resize is an inference-only path)')
         cols = torch.zeros(Bn * ntok, 768, device=img.device, dtype=_T(code))
         K.im2col_patch16(img, cols, code, pad_cls=True)
-        tokens = torch.empty(Bn, ntok, E, device=img.device, dtype=torch.float32)
+        tokens = torch.empty(Bn, ntok, E, device=img.device, dtype=_R(code))
         posf = store.phys(pos)
-        K.gemm(cols, store.shadow(w), Bn * ntok, E, 768, 768, 768, code, bias=store.phys(b), out_f32=tokens, ldo_f32=E,
-               pos_period=ntok, pos=posf)
+        _gemm_resid(cols, store.shadow(w), Bn * ntok, E, 768, code, store.phys(b), None, tokens, pos_period=ntok, pos=posf)
         K.cls_pos(store.phys(cls), posf, tokens)
         ctx.store, ctx.cols, ctx.dims = store, cols, (Bn, ntok, E)
         ctx.prm = (w, b, cls, pos)
@@ -273,9 +287,9 @@ class PatchEmbedFn(Function):
         Bn, ntok, E = ctx.dims
         w, b, cls, pos = ctx.prm
         dtok = dtok.contiguous()
-        dt_t = _as_T(dtok, code)
+        dt_t = dtok if dtok.dtype == _T(code) else _as_T(dtok, code)
         _wgrad(dt_t, cols, E, 768, Bn * ntok, E, 768, store.grad_phys(w), code)
-        K.colsum(dtok, E, Bn * ntok, E, store.grad_phys(b), F32, skip_period=ntok)
+        K.colsum(dtok, E, Bn * ntok, E, store.grad_phys(b), BF16 if dtok.dtype == torch.bfloat16 else F32, skip_period=ntok)
         K.tokens_bwd(dtok, store.grad_phys(pos), store.grad_phys(cls))
         ctx.cols = None
         store.node_done()
@@ -304,18 +318,21 @@ class LayerFn(Function):
         ctxv = torch.empty(M, E, device=dev, dtype=T)
         lse = torch.empty(Bn, num_heads, N, device=dev)
         K.attention_fwd(qkv, ctxv, lse, Bn, N, num_heads, code, bias_u=bias_u, row_flag=row_flag, bias_w=bias_w)
-        x1 = torch.empty(Bn, N, E, device=dev)
-        K.gemm(ctxv, store.shadow(wo), M, E, E, E, E, code, bias=store.phys(bo), resid=x, ldr=E, out_f32=x1, ldo_f32=E)
+        R = x.dtype
+        x1 = torch.empty(Bn, N, E, device=dev, dtype=R)
+        _gemm_resid(ctxv, store.shadow(wo), M, E, E, code, store.phys(bo), x, x1)
         xn2 = torch.empty(M, E, device=dev, dtype=T)
         mean2 = torch.empty(M, device=dev); rstd2 = torch.empty(M, device=dev)
         K.layernorm_fwd(x1, store.phys(g2), store.phys(b2), xn2, mean2, rstd2, M, E, code, eps)
-        z = torch.empty(M, F_, device=dev, dtype=T)
+        need_grad = any(ctx.needs_input_grad)
+        # gelu'(z) is written only when a backward pass will read it (never on the teacher / inference path)
+        z = torch.empty(M, F_, device=dev, dtype=T) if need_grad else None
         a = torch.empty(M, F_, device=dev, dtype=T)
-        K.gemm(xn2, store.shadow(w1), M, F_, E, E, E, code, bias=store.phys(bf1), out_t=a, ldo_t=F_, out_pre=z, ldo_pre=F_,
+        K.gemm(xn2, store.shadow(w1), M, F_, E, E, E, code, bias=store.phys(bf1), out_t=a, ldo_t=F_, out_pre=z, ldo_pre=F_ if need_grad else 0,
                act=K.ACT_GELU)
-        x2 = torch.empty(Bn, N, E, device=dev)
-        K.gemm(a, store.shadow(w2), M, E, F_, F_, F_, code, bias=store.phys(bf2), resid=x1, ldr=E, out_f32=x2, ldo_f32=E)
-        if any(ctx.needs_input_grad):
+        x2 = torch.empty(Bn, N, E, device=dev, dtype=R)
+        _gemm_resid(a, store.shadow(w2), M, E, F_, code, store.phys(bf2), x1, x2)
+        if need_grad:
             ctx.store, ctx.prm = store, prm
             ctx.range = store.range_of(prm)
             store.range_acquire(ctx.range)
@@ -335,7 +352,8 @@ class LayerFn(Function):
         M = Bn * N
         dev = g2.device
         g2 = g2.contiguous()
-        g2t = _as_T(g2, code)
+        R = g2.dtype                              # residual-stream type: the gradient stream has it too
+        g2t = g2 if R == T else _as_T(g2, code)
         g2cs = _handed_colsum(g2)
         # ---- FFN
         # The four weight gradients of the layer go out as ONE grouped launch on the side stream once the last operand
@@ -356,8 +374,8 @@ class LayerFn(Function):
                 K.colsum(dz, F_, M, F_, store.grad_phys(bf1), code)
         dxn2 = torch.empty(M, E, device=dev, dtype=T)
         _dgrad(dz, w1, M, E, F_, store, code, out_t=dxn2, ldo_t=E)
-        g1 = torch.empty(Bn, N, E, device=dev)
-        g1t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
+        g1 = torch.empty(Bn, N, E, device=dev, dtype=R)
+        g1t = torch.empty(Bn, N, E, device=dev, dtype=T) if (code == BF16 and R != T) else None
         # the column sums of g1 (= the proj bias gradient) come out of the same pass
         K.layernorm_bwd(dxn2, sv['x1'], sv['mean2'], sv['rstd2'], store.phys(gm2), g2, g1, g1t, store.grad_phys(gm2),
                         store.grad_phys(b2), M, E, code, dcolsum=store.grad_phys(bo))
@@ -379,8 +397,8 @@ class LayerFn(Function):
         dxn = torch.empty(M, E, device=dev, dtype=T)
         _dgrad(dqkv, wqkv, M, E, 3 * E, store, code, out_t=dxn, ldo_t=E)
         del dqkv, dz
-        g0 = torch.empty(Bn, N, E, device=dev)
-        g0t = torch.empty(Bn, N, E, device=dev, dtype=T) if code == BF16 else None
+        g0 = torch.empty(Bn, N, E, device=dev, dtype=R)
+        g0t = torch.empty(Bn, N, E, device=dev, dtype=T) if (code == BF16 and R != T) else None
         g0cs = zeros_small(E, dev)
         K.layernorm_bwd(dxn, sv['x'], sv['mean1'], sv['rstd1'], store.phys(gm1), g1, g0, g0t, store.grad_phys(gm1),
                         store.grad_phys(b1), M, E, code, dcolsum=g0cs)
@@ -647,7 +665,7 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
                    conv=(Bn, h, w, Cc, -1))
         del dy
     gh, gw = hp['grid']
-    dtok = torch.empty(Bn, ntok, E, device=dev)
+    dtok = torch.empty(Bn, ntok, E, device=dev, dtype=tokens.dtype)
     dtok[:, 0].zero_()                               # the head drops the cls row: only it needs zeros, the rest is written below
     K.layernorm_bwd(dcur, tokens[:, 1:], sv['mean0'], sv['rstd0'], store.phys(hp['norm_w']), None, dtok[:, 1:], None,
                     store.grad_phys(hp['norm_w']), store.grad_phys(hp['norm_b']), Bn * gh * gw, E, code,

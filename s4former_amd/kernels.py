@@ -120,6 +120,15 @@ def _tune_gemm(key, run, candidates):
     return best
 
 
+def _xcode(t):
+    """dtype code of a residual-stream tensor (fp32 | bf16)"""
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise S4FError(f'residual-stream tensors are fp32 or bf16, got {t.dtype}')
+
+
 def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=1.0, bias=None, resid=None, ldr=0,
          out_f32=None, ldo_f32=0, out_t=None, ldo_t=0, out_pre=None, ldo_pre=0, aux=None, ld_aux=0, act=ACT_NONE,
          atomic=False, splitk=1, conv=None, pos_period=0, pos=None, tile_hint=0, colsum=None, colstats=None):
@@ -134,6 +143,8 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
     if tile_hint == 0 and dtype == BF16 and AUTOTUNE:
         key = (a_mode, b_mode, M, N, K, lda, ldb, conv, act, bool(atomic), out_f32 is not None, out_t is not None,
                resid is not None, splitk)
+        if resid is not None and resid.dtype == torch.bfloat16:
+            key = key + ('resid_t',)
         choice = _tuned_lookup(key)
         if choice is None and L._prof is not None:
             choice = (0, splitk)
@@ -176,7 +187,13 @@ def _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, re
                  out_pre, ldo_pre, aux, ld_aux, act, atomic, splitk, conv, pos_period, pos, tile_hint, colsum=None):
     _chk_dtype(A, dtype, 'gemm A'); _chk_dtype(B, dtype, 'gemm B')
     _chk_dtype(out_t, dtype, 'gemm out_t'); _chk_dtype(out_pre, dtype, 'gemm out_pre'); _chk_dtype(aux, dtype, 'gemm aux')
-    _chk_f32(bias, 'gemm bias'); _chk_f32(resid, 'gemm resid'); _chk_f32(out_f32, 'gemm out_f32'); _chk_f32(pos, 'gemm pos')
+    _chk_f32(bias, 'gemm bias'); _chk_f32(out_f32, 'gemm out_f32'); _chk_f32(pos, 'gemm pos')
+    resid_t = resid is not None and resid.dtype == torch.bfloat16
+    if resid_t:
+        if dtype != BF16 or out_t is None:
+            raise S4FError('gemm: a bf16 residual needs bf16 mode and a T output')
+    else:
+        _chk_f32(resid, 'gemm resid')
     cB = cH = cW = cC = 0
     csign = 1
     if conv is not None:
@@ -216,6 +233,7 @@ def _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, re
     d.cB, d.cH, d.cW, d.cC, d.csign = cB, cH, cW, cC, csign
     d.alpha = alpha
     d.bias, d.resid, d.ldr = p(bias), p(resid), ldr
+    d.resid_t = 1 if resid_t else 0
     d.out_f32, d.ldo_f32 = p(out_f32), ldo_f32
     d.out_t, d.ldo_t = p(out_t), ldo_t
     d.out_pre, d.ldo_pre = p(out_pre), ldo_pre
@@ -322,16 +340,18 @@ def im2col_patch16(img, cols, dtype, pad_cls=False):
 
 def cls_pos(cls, pos, tokens):
     B, ntok, C = tokens.shape
-    for t, n in ((cls, C), (pos, ntok * C), (tokens, B * ntok * C)):
+    for t, n in ((cls, C), (pos, ntok * C)):
         _chk_f32(t, 'cls_pos'); _need(t, n, 'cls_pos')
-    call('s4f_cls_pos', p(cls), p(pos), p(tokens), B, ntok, C, stream())
+    _need(tokens, B * ntok * C, 'cls_pos')
+    call('s4f_cls_pos', p(cls), p(pos), p(tokens), B, ntok, C, _xcode(tokens), stream())
 
 
 def tokens_bwd(dtok, dpos, dcls):
     B, ntok, C = dtok.shape
-    for t, n in ((dcls, C), (dpos, ntok * C), (dtok, B * ntok * C)):
+    for t, n in ((dcls, C), (dpos, ntok * C)):
         _chk_f32(t, 'tokens_bwd'); _need(t, n, 'tokens_bwd')
-    call('s4f_tokens_bwd', p(dtok), p(dpos), p(dcls), B, ntok, C, stream())
+    _need(dtok, B * ntok * C, 'tokens_bwd')
+    call('s4f_tokens_bwd', p(dtok), p(dpos), p(dcls), B, ntok, C, _xcode(dtok), stream())
 
 
 def colsum(X, ld, M, N, out, dtype, skip_period=0):
@@ -352,12 +372,15 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, C, dtype, eps, rows_per_i
         rows_per_img, in_batch_stride = rows, 0
     if rows % rows_per_img:
         raise S4FError('layernorm_fwd: rows must be a multiple of rows_per_img')
-    _chk_f32(x, 'ln x'); _chk_f32(gamma, 'ln gamma'); _chk_f32(beta, 'ln beta'); _chk_dtype(y, dtype, 'ln y')
+    xd = _xcode(x)
+    if xd == BF16 and dtype != BF16:
+        raise S4FError('layernorm_fwd: a bf16 residual stream exists in bf16 mode only')
+    _chk_f32(gamma, 'ln gamma'); _chk_f32(beta, 'ln beta'); _chk_dtype(y, dtype, 'ln y')
     _chk_f32(mean, 'ln mean'); _chk_f32(rstd, 'ln rstd')
     _need_span(x, _ln_extent(rows, C, rows_per_img, in_batch_stride), 'ln x'); _need(y, rows * C, 'ln y')
     _need(gamma, C, 'ln gamma'); _need(beta, C, 'ln beta'); _need(mean, rows, 'ln mean'); _need(rstd, rows, 'ln rstd')
     call('s4f_layernorm_fwd', p(x), p(gamma), p(beta), p(y), p(mean), p(rstd), rows, C, rows_per_img, in_batch_stride,
-         eps, dtype, stream())
+         eps, dtype, xd, stream())
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dresid, dx, dx_t, dgamma, dbeta, rows, C, dtype, rows_per_img=0,
@@ -368,7 +391,13 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dresid, dx, dx_t, dgamma, dbeta, row
         raise S4FError('layernorm_bwd: rows must be a multiple of rows_per_img')
     nin = _ln_extent(rows, C, rows_per_img, in_batch_stride)
     _chk_dtype(dy, dtype, 'ln_bwd dy'); _chk_dtype(dx_t, dtype, 'ln_bwd dx_t')
-    for t in (x, mean, rstd, gamma, dresid, dx, dgamma, dbeta):
+    xd = _xcode(x)
+    for t in (dresid, dx):
+        if t is not None and _xcode(t) != xd:
+            raise S4FError('layernorm_bwd: x, dresid and dx share the residual-stream dtype')
+    if xd == BF16 and (dtype != BF16 or dx_t is not None):
+        raise S4FError('layernorm_bwd: a bf16 residual stream exists in bf16 mode only and needs no dx_t')
+    for t in (mean, rstd, gamma, dgamma, dbeta):
         _chk_f32(t, 'ln_bwd')
     _need(dy, rows * C, 'ln_bwd dy'); _need_span(x, nin, 'ln_bwd x'); _need_span(dx, nin, 'ln_bwd dx')
     _need_span(dresid, nin, 'ln_bwd dresid'); _need_span(dx_t, nin, 'ln_bwd dx_t')
@@ -376,7 +405,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dresid, dx, dx_t, dgamma, dbeta, row
     _need(gamma, C, 'ln_bwd gamma'); _need(dgamma, C, 'ln_bwd dgamma'); _need(dbeta, C, 'ln_bwd dbeta')
     _chk_f32(dcolsum, 'ln_bwd dcolsum'); _need(dcolsum, C if dcolsum is not None else 0, 'ln_bwd dcolsum')
     call('s4f_layernorm_bwd', p(dy), p(x), p(mean), p(rstd), p(gamma), p(dresid), p(dx), p(dx_t), p(dgamma), p(dbeta),
-         p(dcolsum), rows, C, rows_per_img, in_batch_stride, 1 if accumulate else 0, dtype, stream())
+         p(dcolsum), rows, C, rows_per_img, in_batch_stride, 1 if accumulate else 0, dtype, xd, stream())
 
 
 def add_f32(a, b, out, out_t, dtype):
@@ -592,11 +621,13 @@ def cutmix_labels(labels, out, box):
 
 
 def gather_rows(src, out, row_map, rows, C):
-    _chk_f32(src, 'gather_rows src'); _chk_f32(out, 'gather_rows out')
+    xd = _xcode(src)
+    if out.dtype != src.dtype:
+        raise S4FError('gather_rows: src and out must have the same dtype')
     _need(out, rows * C, 'gather_rows out'); _need(src, rows * C, 'gather_rows src'); _chk_i32(row_map, rows, 'gather_rows map')
-    if C % 4:
-        raise S4FError('gather_rows: C must be a multiple of 4')
-    call('s4f_gather_rows', p(src), p(out), p(row_map), rows, C, stream())
+    if C % (8 if xd == BF16 else 4):
+        raise S4FError('gather_rows: rows must be whole 16-byte chunks')
+    call('s4f_gather_rows', p(src), p(out), p(row_map), rows, C, xd, stream())
 
 
 def resize_bilinear(x, size, align_corners=False, window=None):

@@ -140,7 +140,18 @@ def grad_sample(g, ns=NS):
     return f[::step][:ns]
 
 
-def check_grad_samples(z, it, named_grads, tol, msgs, label=''):
+# ------------------------------------------------------------------------------------------------ measured parity margins
+# Every step / full-size test RECORDS what it measured (not only pass / fail): tests/conftest.py writes the records of a
+# session to gpurun_out/parity_report.json, the copy of a GPU run is committed as profiles/r03_parity_report.json, and the
+# bf16 bounds of the tests are set from it (<= 3 x the measured value).
+PARITY = {}
+
+
+def record(section, **kv):
+    PARITY.setdefault(section, {}).update({k: (float(v) if isinstance(v, (int, float, np.floating)) else v) for k, v in kv.items()})
+
+
+def check_grad_samples(z, it, named_grads, tol, msgs, label='', rec=None, mtol=None, noise=None):
     """Element-wise comparison of EVERY parameter's gradient with the golden samples, relative to the tensor's largest element.
 
     Iteration 0 is held against the reference's FLOAT64 evaluation of the same step (`it0_gs64`): |got - ref64| <= max(tol, 8 D)
@@ -153,7 +164,8 @@ def check_grad_samples(z, it, named_grads, tol, msgs, label=''):
     bf16 perf mode (tol >= 0.1, a noise regime: one ReLU decided the other way moves a BatchNorm bias gradient of the tiny model
     by a large fraction of its maximum, and the fp32 atomics of split-K sums make WHICH decisions flip vary from run to run -
     the worst tensor of `mt_ours`, iteration 1, came out at 0.52 in one of four runs of one build and below 0.5 in the others): `tol` bounds the 90th percentile over the
-    tensors, the single worst tensor may reach 2 tol; the median bound (tol / 10) is what holds the bulk."""
+    tensors, the single worst tensor may reach 3 tol; the median bound (`mtol`, default tol / 10) is what holds the bulk.
+    Measured values are recorded under `rec` (profiles/r03_parity_report.json)."""
     keys = [str(k) for k in z[f'it{it}_gn_keys']]
     gs, gmax = z[f'it{it}_gs'], z[f'it{it}_gmax']
     ref, D, Dmed = gs, 0.0, 0.0
@@ -161,23 +173,38 @@ def check_grad_samples(z, it, named_grads, tol, msgs, label=''):
         ref = z['it0_gs64']
         d = np.abs(gs.astype(np.float64) - ref).max(axis=1) / (gmax + 1e-30)
         D, Dmed = float(d.max()), float(np.median(d))
+    elif it == 0 and noise is not None:
+        # fixtures without an fp64 evaluation (the full-batch ones: it does not fit the build container): the reference's
+        # fp32-vs-fp64 distance is taken from the small-batch fixture of the same model (reference_noise)
+        D, Dmed = noise
     errs = []
     for i, k in enumerate(keys):
         got = grad_sample(named_grads[k], gs.shape[1]).double().cpu().numpy()
         errs.append(float(np.abs(got - ref[i, :got.size]).max()) / (float(gmax[i]) + 1e-30))
     w = int(np.argmax(errs))
-    bound, mbound = max(tol, 8 * D), max(tol / 10, 4 * Dmed)
+    if rec is not None:
+        record(rec, **{f'it{it}_grad_elem_worst': errs[w], f'it{it}_grad_elem_worst_tensor': keys[w],
+                       f'it{it}_grad_elem_p90': float(np.percentile(errs, 90)), f'it{it}_grad_elem_median': float(np.median(errs)),
+                       f'it{it}_reference_fp32_vs_fp64_worst': D, f'it{it}_reference_fp32_vs_fp64_median': Dmed})
+    bound, mbound = max(tol, 8 * D), max(tol / 10 if mtol is None else mtol, 4 * Dmed)
     if tol >= 0.1:
         p90 = float(np.percentile(errs, 90))
         if p90 > bound:
             msgs.append(f'{label}it{it} gradient elements, 90th percentile over tensors: {p90:.2e} (bound {bound:.1e})')
-        bound = 2 * bound
+        bound = 3 * bound
     if errs[w] > bound:
         msgs.append(f'{label}it{it} gradient elements of {keys[w]}: {errs[w]:.2e} of the tensor maximum (bound {bound:.1e}; the '
                     f"reference's own fp32 is {D:.1e} from its fp64 evaluation)")
     if float(np.median(errs)) > mbound:
         msgs.append(f'{label}it{it} gradient elements, median over tensors: {float(np.median(errs)):.2e} (bound {mbound:.1e})')
     return errs[w], keys[w], float(np.median(errs)), D
+
+
+def reference_noise(z):
+    """(worst, median) over tensors of the reference's own fp32 gradient samples' distance from its fp64 evaluation"""
+    gs, gmax, ref = z['it0_gs'], z['it0_gmax'], z['it0_gs64']
+    d = np.abs(gs.astype(np.float64) - ref).max(axis=1) / (gmax + 1e-30)
+    return float(d.max()), float(np.median(d))
 
 
 def fragile_pixels(z, logit_tol, th=0.95):

@@ -133,7 +133,10 @@ import numpy as np  # noqa: E402
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 TOL = {   # (loss it0, loss it1, grad-norm it0, it1, grad-element it0, it1, final |.|_1, logit bound for the tie set)
     'fp32': (1e-4, 1e-3, 2e-3, 5e-3, 1e-4, 5e-2, 2e-4, 2e-5),
-    'bf16': (2e-2, 4e-2, 8e-2, 1.5e-1, 5e-1, 5e-1, 2e-2, 2e-2),
+    # bf16 (round 3): <= 3 x the values measured at DeiT-B size with the bf16 residual stream (profiles/r03_parity_report.json):
+    # losses 6.1e-3 / 8.5e-4, gradient norms 1.8e-2 / 1.9e-2, gradient elements 90th percentile 8.8e-2 (bound 0.25; the worst
+    # tensor, measured 0.17, may reach 3 x that; the median, measured 5.1e-2, is held to 0.1), pseudo-labels 1.26 % differ (3.5 %)
+    'bf16': (1.8e-2, 5e-3, 5.5e-2, 5.5e-2, 2.5e-1, 2.5e-1, 2e-2, 2e-2),
 }
 
 
@@ -185,11 +188,13 @@ def _golden_run(name, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-@pytest.mark.parametrize('name', ['full_sup', 'full_pasa', 'full_768', 'full_ours'])
+@pytest.mark.parametrize('name', ['full_sup', 'full_pasa', 'full_768', 'full_ours', 'full_sup8', 'full_semi4'])
 def test_fullsize_step_vs_reference_golden(name, dtype, monkeypatch):
     import s4former_amd as S
     from tests import common as C
-    if dtype == 'fp32' and name != 'full_sup':
+    if not os.path.exists(os.path.join(GOLD, f'{name}.npz')):
+        pytest.skip(f'{name}.npz not generated')
+    if dtype == 'fp32' and name not in ('full_sup', 'full_sup8'):
         # PASA flags the less-confident half of the patches with torch.topk; at 1024 / 2304 patches the boundary value is tied
         # for these batches, and WHICH tied patch is returned is implementation-defined (CPU nth_element vs GPU radix select).
         # To compare with the CPU reference the tied choice is taken from the CPU implementation (a debugging switch of the
@@ -201,15 +206,20 @@ def test_fullsize_step_vs_reference_golden(name, dtype, monkeypatch):
         S.set_compute_dtype('fp32')
     tl0, tl1, tg0, tg1, te0, te1, tw, tz = TOL[dtype]
     msgs = []
+    from s4former_amd import runtime
+    sec = f'deit_b/{name}/{dtype}' + ('' if dtype == 'fp32' else ('/resid_fp32' if runtime._resid_fp32 else '/resid_bf16'))
     for it in range(max(1, meta['iters'])):
         keys = [str(k) for k in z[f'it{it}_loss_keys']]
         assert sorted(k for k in keys if 'loss' in k) == sorted(k for k in rec[it]['log'] if 'loss' in k and k != 'loss')
+        lerrs = []
         for k, v in zip(keys, z[f'it{it}_loss_vals']):
             if 'loss' in k:
                 e = abs(rec[it]['log'][k] - v) / abs(v)
+                lerrs.append(e)
                 if e > (tl0, tl1)[it]:
                     msgs.append(f'it{it} {k}: {rec[it]["log"][k]:.6f} vs {v:.6f} (rel {e:.2e})')
         e = abs(rec[it]['log']['loss'] - float(z[f'it{it}_loss'])) / abs(float(z[f'it{it}_loss']))
+        C.record(sec, **{f'it{it}_loss_rel_worst': max(lerrs), f'it{it}_loss_rel_median': float(np.median(lerrs)), f'it{it}_total_loss_rel': e})
         if e > (tl0, tl1)[it]:
             msgs.append(f'it{it} total loss rel {e:.2e}')
         if not meta['iters']:
@@ -217,9 +227,13 @@ def test_fullsize_step_vs_reference_golden(name, dtype, monkeypatch):
         gk = [str(k) for k in z[f'it{it}_gn_keys']]
         assert sorted(gk) == sorted(rec[it]['gn']), set(gk) ^ set(rec[it]['gn'])
         worst = max(((abs(rec[it]['gn'][k] - v) / (abs(v) + 1e-12), k) for k, v in zip(gk, z[f'it{it}_gn_vals'])))
+        C.record(sec, **{f'it{it}_grad_norm_rel_worst': worst[0], f'it{it}_grad_norm_worst_tensor': worst[1]})
         if worst[0] > (tg0, tg1)[it]:
             msgs.append(f'it{it} grad norm {worst[1]}: rel {worst[0]:.2e}')
-        w = C.check_grad_samples(z, it, rec[it]['g'], (te0, te1)[it], msgs)
+        noise = None
+        if 'it0_gs64' not in z.files:     # full-batch fixtures: the reference's noise floor from the small-batch fixture of the model
+            noise = C.reference_noise(np.load(os.path.join(GOLD, 'full_sup.npz' if not meta['n_unsup'] else 'full_pasa.npz'), allow_pickle=False))
+        w = C.check_grad_samples(z, it, rec[it]['g'], (te0, te1)[it], msgs, rec=sec, noise=noise, mtol=0.1 if dtype == 'bf16' else None)
         print(f'{name} {dtype} it{it}: worst grad norm {worst[0]:.2e} ({worst[1]}), grad elements: worst {w[0]:.2e} ({w[1]}), median '
               f'{w[2]:.2e}; reference fp32 vs its fp64: {w[3]:.2e}')
     for k, ref in zip(z['final_sha_keys'], z['final_abs_sum']):
@@ -235,14 +249,18 @@ def test_fullsize_step_vs_reference_golden(name, dtype, monkeypatch):
             bad = mism & ~fragile
             print(f'{name} fp32 labels: {int(mism.sum())} of {ref.size} differ, {int(fragile.sum())} ties within {tol:.2e}, '
                   f'{int(bad.sum())} outside the tie set')
+            C.record(sec, labels_total=int(ref.size), labels_differ=int(mism.sum()), labels_in_tie_set=int(fragile.sum()),
+                     labels_differ_outside_tie_set=int(bad.sum()))
             if bad.any():
                 msgs.append(f'{int(bad.sum())} pseudo-label pixels differ outside the tie set')
             if float(fragile.mean()) > 0.01:
                 msgs.append('tie set is not a small minority')
         else:
             print(f'{name} bf16 labels: {float(mism.mean()):.3%} differ')
-            if float(mism.mean()) > 0.05:
+            C.record(sec, labels_total=int(ref.size), labels_differ=int(mism.sum()), labels_differ_fraction=float(mism.mean()))
+            if float(mism.mean()) > 0.035:
                 msgs.append(f'{float(mism.mean()):.2%} of the bf16 pseudo-labels differ from the reference')
+        C.record(sec, mask_ratio=info['ratio'], mask_ratio_reference=float(z['teacher_mask_ratio_final']))
         if abs(info['ratio'] - float(z['teacher_mask_ratio_final'])) > (2e-3 if dtype == 'fp32' else 3e-2):
             msgs.append(f'mask ratio {info["ratio"]:.4f} vs {float(z["teacher_mask_ratio_final"]):.4f}')
     assert not msgs, '\n'.join(msgs[:20])

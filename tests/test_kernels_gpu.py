@@ -875,3 +875,87 @@ def test_cutmix_patchshuffle_gather(K):
     tr = tok.clone().requires_grad_(True)
     (O.repatchmix_tokens(tr[:, 1:], torch.from_numpy(perms), 2) * g[:, 1:]).sum().backward()
     assert torch.equal(t.grad[:, 1:].cpu(), tr.grad[:, 1:]) and torch.equal(t.grad[:, 0].cpu(), g[:, 0])
+
+
+# ------------------------------------------------------------------------------------------------ bf16 residual stream (round 3)
+# In bf16 mode the token tensors between the encoder layers (vit.py:113-127: x, x + attn, x + ffn) and their gradients are
+# kept in bf16: LayerNorm reads / writes them typed, the proj / fc2 GEMMs add a bf16 residual and store the sum as bf16.
+@pytest.mark.parametrize('skip', [0, 1])
+def test_layernorm_bf16_stream(K, skip):
+    code = 1
+    B, ntok, C = 3, 197, 768
+    x = q(rnd(B, ntok, C, seed=1, scale=2.0) + 0.5, code)
+    gamma, beta = rnd(C, seed=2) * 0.1 + 1.0, rnd(C, seed=3) * 0.1
+    xin = x[:, skip:].reshape(-1, C).clone().requires_grad_(True)
+    g, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = O.layernorm(xin, g, bt, 1e-6)
+    rows = xin.shape[0]
+    dy = q(rnd(rows, C, seed=4), code)
+    y.backward(dy)
+    yk = torch.empty(rows, C, device='cuda', dtype=torch.bfloat16)
+    mean, rstd = torch.empty(rows, device='cuda'), torch.empty(rows, device='cuda')
+    xd = dev(x, code)
+    xv = xd[:, skip:]
+    K.layernorm_fwd(xv, dev(gamma), dev(beta), yk, mean, rstd, rows, C, code, 1e-6, rows_per_img=ntok - skip, in_batch_stride=ntok * C)
+    check(yk, y, code, 'layernorm fwd (bf16 x)', tol=1e-2)
+    check(mean, xin.detach().mean(-1), 0, 'ln mean (bf16 x)')
+    dres = q(rnd(B, ntok, C, seed=5), code)
+    dx = torch.zeros(B, ntok, C, device='cuda', dtype=torch.bfloat16)
+    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    dcs = torch.zeros(C, device='cuda')
+    K.layernorm_bwd(dev(dy, code), xv, mean, rstd, dev(gamma), dev(dres, code)[:, skip:], dx[:, skip:], None, dg, db, rows, C, code,
+                    rows_per_img=ntok - skip, in_batch_stride=ntok * C, dcolsum=dcs)
+    ref_dx = (xin.grad.reshape(B, ntok - skip, C) + dres[:, skip:])
+    check(dx[:, skip:], ref_dx, code, 'layernorm dx (+resid), bf16 stream', tol=1e-2)
+    check(dcs, ref_dx.reshape(-1, C).sum(0), code, 'column sums of dx (fp32 values before the rounding)', tol=1e-2)
+    check(dg, g.grad, code, 'dgamma', tol=1e-2)
+    check(db, bt.grad, code, 'dbeta', tol=1e-2)
+    if skip:
+        assert float(dx[:, 0].float().abs().max()) == 0.0, 'the skipped cls rows must stay untouched'
+    with pytest.raises(Exception):
+        K.layernorm_fwd(xv, dev(gamma), dev(beta), torch.empty(rows, C, device='cuda'), mean, rstd, rows, C, 0, 1e-6,
+                        rows_per_img=ntok - skip, in_batch_stride=ntok * C)       # a bf16 stream exists in bf16 mode only
+
+
+@pytest.mark.parametrize('hint', [0, 8, 10])
+@pytest.mark.parametrize('M,N,K_', [(2 * 1025, 768, 768), (1030, 768, 3072), (300, 256, 512)])
+def test_gemm_bf16_residual(K, hint, M, N, K_):
+    code = 1
+    if hint == 8 and N % 192:
+        pytest.skip('256 x 192 tiles need N % 192 == 0')
+    x, w, b = q(rnd(M, K_, seed=1), code), q(rnd(N, K_, seed=2, scale=0.03), code), rnd(N, seed=3)
+    r = q(rnd(M, N, seed=4, scale=2.0), code)
+    ref = r + O.linear(x, w, b)
+    out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), resid=dev(r, code), ldr=N, out_t=out, ldo_t=N, tile_hint=hint)
+    check(out, ref, code, f'bf16 residual epilogue, hint {hint}', tol=1e-2)
+    with pytest.raises(Exception):       # a bf16 residual needs a T output
+        K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, resid=dev(r, code), ldr=N, out_f32=torch.empty(M, N, device='cuda'), ldo_f32=N)
+
+
+def test_patch_embed_bf16_tokens(K):
+    code = 1
+    B, H, W = 2, 64, 96
+    img = rnd(B, 3, H, W, seed=1)
+    w, b = q(rnd(768, 3, 16, 16, seed=2, scale=0.05), code), rnd(768, seed=3)
+    cls, pos = rnd(1, 1, 768, seed=4), rnd(1, 1 + (H // 16) * (W // 16), 768, seed=5)
+    patches, hw = O.patch_embed(q(img, code), w, b)
+    ref = O.assemble_tokens(patches, cls, pos)
+    tpi = hw[0] * hw[1]
+    cols = torch.zeros(B * (tpi + 1), 768, device='cuda', dtype=torch.bfloat16)
+    K.im2col_patch16(dev(img), cols, code, pad_cls=True)
+    tokens = torch.zeros(B, tpi + 1, 768, device='cuda', dtype=torch.bfloat16)
+    K.gemm(cols, dev(w.reshape(768, 768), code), B * (tpi + 1), 768, 768, 768, 768, code, bias=dev(b), out_t=tokens, ldo_t=768,
+           pos_period=tpi + 1, pos=dev(pos.reshape(-1, 768)))
+    K.cls_pos(dev(cls.reshape(-1)), dev(pos.reshape(-1, 768)), tokens)
+    check(tokens, ref, code, 'patch embed + token assembly, bf16 tokens', tol=1e-2)
+    dtok = q(rnd(B, tpi + 1, 768, seed=6), code)
+    dpos, dcls = torch.zeros(tpi + 1, 768, device='cuda'), torch.zeros(768, device='cuda')
+    K.tokens_bwd(dev(dtok, code), dpos, dcls)
+    check(dpos, dtok.sum(0), 0, 'dpos from bf16 gradients')
+    check(dcls, dtok[:, 0].sum(0), 0, 'dcls from bf16 gradients')
+    src = dev(q(rnd(40, 768, seed=7), code), code)
+    perm = torch.randperm(40, generator=torch.Generator().manual_seed(8)).to(torch.int32).cuda()
+    out = torch.empty_like(src)
+    K.gather_rows(src, out, perm, 40, 768)
+    assert torch.equal(out.cpu(), src.cpu()[perm.cpu().long()]), 'bf16 row gather'

@@ -23,6 +23,11 @@ class _SampleView(dict):
     """the recorded samples ARE the strided samples already: C.grad_sample of a 64-element vector returns it unchanged"""
 
 
+def _resid_name():
+    from s4former_amd import runtime
+    return 'bf16' if runtime.residual_dtype() == 1 else 'fp32'
+
+
 def load_gold(name):
     z = np.load(os.path.join(GOLD, f'step_{name}.npz'), allow_pickle=False)
     return z, json.loads(str(z['meta']))
@@ -70,7 +75,7 @@ def test_unfused_head_paths_still_agree_with_the_golden(dtype, monkeypatch):
     z, meta = load_gold('mt_pasa')
     model, opt, sched = build_product(meta, dtype)
     rec = run_product(model, opt, sched, meta, iters=1)
-    ltol, gtol = {'fp32': (1e-4, 1e-3), 'bf16': (2e-2, 8e-2)}[dtype]
+    ltol, gtol = {'fp32': (1e-4, 1e-3), 'bf16': (5e-3, 6e-2)}[dtype]
     for k, v in zip([str(k) for k in z['it0_loss_keys']], z['it0_loss_vals']):
         if 'loss' in k:
             assert abs(rec[0]['log'][k] - v) <= ltol * abs(v), (k, rec[0]['log'][k], v)
@@ -84,21 +89,29 @@ def test_step_vs_golden(name, dtype):
     z, meta = load_gold(name)
     model, opt, sched = build_product(meta, dtype)
     rec = run_product(model, opt, sched, meta)
-    ltol = {'fp32': (1e-4, 1e-3), 'bf16': (2e-2, 4e-2)}[dtype]
-    gtol = {'fp32': (1e-3, 5e-3), 'bf16': (8e-2, 1.5e-1)}[dtype]
-    etol = {'fp32': (1e-4, 2e-2), 'bf16': (5e-1, 5e-1)}[dtype]      # (worst tensor; the median over tensors is held to a tenth)
+    # bf16 bounds (round 3): <= 3 x what profiles/r03_parity_report.json measured on the tiny fixtures with the bf16 residual
+    # stream - losses 9.4e-4 / 3.9e-3, gradient norms 2.0e-2 / 2.3e-2, gradient elements (of the tensor maximum): 90th percentile
+    # over the tensors 9.8e-2, median 5.1e-2, worst tensor 0.31 (a BatchNorm bias whose ReLU decisions flip: noise, see
+    # check_grad_samples; bound 3 x the 90th-percentile bound)
+    ltol = {'fp32': (1e-4, 1e-3), 'bf16': (3e-3, 1.2e-2)}[dtype]
+    gtol = {'fp32': (1e-3, 5e-3), 'bf16': (6e-2, 7e-2)}[dtype]
+    etol = {'fp32': (1e-4, 2e-2), 'bf16': (2.5e-1, 2.5e-1)}[dtype]    # (bf16: 90th percentile over the tensors; worst tensor 3 x, median 0.1)
     msgs = []
+    sec = f'tiny/{name}/{dtype}' + ('' if dtype == 'fp32' else f'/resid_{_resid_name()}')
     for it in range(2):
         keys = [str(k) for k in z[f'it{it}_loss_keys']]
         vals = z[f'it{it}_loss_vals']
         got_keys = sorted(k for k in rec[it]['log'] if 'loss' in k and k != 'loss')
         assert got_keys == sorted(k for k in keys if 'loss' in k), (got_keys, keys)
+        lerrs = []
         for k, v in zip(keys, vals):
             if 'loss' in k:
                 e = abs(rec[it]['log'][k] - v) / abs(v)
+                lerrs.append(e)
                 if e > ltol[it]:
                     msgs.append(f'it{it} {k}: {rec[it]["log"][k]:.6f} vs {v:.6f} (rel {e:.2e})')
         e = abs(rec[it]['log']['loss'] - float(z[f'it{it}_loss'])) / abs(float(z[f'it{it}_loss']))
+        C.record(sec, **{f'it{it}_loss_rel_worst': max(lerrs), f'it{it}_loss_rel_median': float(np.median(lerrs)), f'it{it}_total_loss_rel': e})
         if e > ltol[it]:
             msgs.append(f'it{it} total loss rel {e:.2e}')
         worst = (0.0, None)
@@ -108,11 +121,12 @@ def test_step_vs_golden(name, dtype):
             e = abs(rec[it]['gn'][k] - v) / (abs(v) + 1e-12)
             if e > worst[0]:
                 worst = (e, k)
+        C.record(sec, **{f'it{it}_grad_norm_rel_worst': worst[0], f'it{it}_grad_norm_worst_tensor': worst[1]})
         if worst[0] > gtol[it]:
             msgs.append(f'it{it} grad norm {worst[1]}: rel {worst[0]:.2e}')
         # ELEMENTS of every parameter's gradient (64 strided samples each, incl. in_proj, out_proj, fc1 / fc2, conv 3x3, BN
         # gamma / beta, pos_embed): north_star's 1e-4 in fp32 at iteration 0, relative to the tensor's largest element
-        C.check_grad_samples(z, it, _SampleView(rec[it]['g']), etol[it], msgs)
+        C.check_grad_samples(z, it, _SampleView(rec[it]['g']), etol[it], msgs, rec=sec, mtol=0.1 if dtype == 'bf16' else None)
     # state after two optimiser steps (student and EMA teacher)
     sd = model.state_dict()
     wtol = 2e-4 if dtype == 'fp32' else 2e-2
