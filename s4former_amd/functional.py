@@ -30,6 +30,10 @@ LOGIT_LD = 32   # channel stride of the low-resolution logits buffers (>= num_cl
 # arena), so they are enqueued on a second HIP stream: they fill the CUs that the tail of each chain kernel leaves
 # idle (tile-count quantisation: 768..1152 tiles over 256 CUs).  The optimiser / gradient reducer joins the stream.
 USE_SIDE_STREAM = os.environ.get('S4F_SIDE_STREAM', '1') != '0'
+# A/B switch (round 3): the grouped weight gradient of an encoder layer on the side stream (1) or inside the backward chain (0).
+# A block of the 8-wave GEMMs holds a CU's whole register file (2 waves x 256 registers per SIMD): while the 216 blocks of the
+# grouped weight gradient are resident, the chain's kernels run on the 40 CUs that are left.
+LAYER_WG_SIDE = os.environ.get('S4F_LAYER_WG_SIDE', '1') != '0'
 _side = {}
 
 
@@ -132,11 +136,12 @@ class on_side:
     """with on_side(dev, t1, t2, ...): kernels launched inside run on the side stream after everything already enqueued
     on the current stream; the tensors are kept alive for the side stream (caching-allocator record_stream)."""
 
-    def __init__(self, device, *tensors):
+    def __init__(self, device, *tensors, enable=True):
         self.dev, self.tensors = device, tensors
+        self.enable = enable and USE_SIDE_STREAM
 
     def __enter__(self):
-        if not USE_SIDE_STREAM:
+        if not self.enable:
             return self
         self.side = side_stream(self.dev)
         self.side.wait_stream(torch.cuda.current_stream())
@@ -145,7 +150,7 @@ class on_side:
         return self
 
     def __exit__(self, *exc):
-        if not USE_SIDE_STREAM:
+        if not self.enable:
             return False
         self.ctx.__exit__(*exc)
         for t in self.tensors:
@@ -388,7 +393,7 @@ class LayerFn(Function):
         delta = torch.empty(Bn, H, N, device=dev)
         K.attention_bwd(sv['qkv'], sv['ctxv'], dctx, sv['lse'], delta, dqkv, Bn, N, H, code, bias_u=sv['bias_u'],
                         row_flag=sv['row_flag'], bias_w=bias_w)
-        with on_side(dev, dqkv, xn, dz, xn2, g1t, ctxv, g2t, a_act):
+        with on_side(dev, dqkv, xn, dz, xn2, g1t, ctxv, g2t, a_act, enable=LAYER_WG_SIDE):
             K.wgrad_grouped([(dz, xn2, F_, E, M, store.grad_phys(w1)),
                              (g2t, a_act, E, F_, M, store.grad_phys(w2)),
                              (dqkv, xn, 3 * E, E, M, store.grad_phys(wqkv)),

@@ -27,10 +27,11 @@ def compute_dtype_name():
     return 'bf16' if _code == BF16 else 'fp32'
 
 
-# Residual stream (token tensors between the encoder layers and their gradients, vit.py:113-127): fp32 in parity mode; in
-# bf16 mode it is kept in bf16 since round 3 (the proj / fc2 GEMM epilogues and both LayerNorm passes were HBM-bound on the
-# fp32 residual traffic).  S4F_RESID=fp32 keeps it in fp32 in bf16 mode too (A/B switch, round-2 behaviour).
-_resid_fp32 = os.environ.get('S4F_RESID', 'auto').lower() in ('fp32', 'f32', 'float32')
+# Residual stream (token tensors between the encoder layers and their gradients, vit.py:113-127): fp32 in both modes by
+# default.  S4F_RESID=bf16 keeps it in bf16 in bf16 mode (kernels and tests exist: round 3).  Measured on the default workload
+# (profiles/r03_*): the step gains 0.24 ms (30.76 -> 30.51 ms: the LayerNorm passes are latency-bound, not HBM-bound) while the
+# gradient arena's cosine against the fp32 step falls from 0.99995 to 0.9987 (relative error ~1 % -> ~5 %) - not worth it.
+_resid_fp32 = os.environ.get('S4F_RESID', 'fp32').lower() not in ('bf16', 'bfloat16')
 
 
 def set_residual_fp32(flag):

@@ -96,7 +96,9 @@ def test_bf16_step_agrees_with_fp32_step(runs):
     cos = float((g0 * g1).sum() / (g0.norm() * g1.norm()))
     ratio = float(g1.norm() / g0.norm())
     print(f'full-size gradient arena: cosine {cos:.5f}, norm ratio {ratio:.4f}')
-    assert cos > 0.999 and 0.99 < ratio < 1.01      # measured: 0.99995, 0.9985
+    from tests import common as C
+    C.record('deit_b/bf16_vs_fp32_step', **{f'grad_arena_cosine_{len(f32["losses"])}_losses': cos, f'grad_arena_norm_ratio_{len(f32["losses"])}_losses': ratio})
+    assert cos > 0.9995 and 0.99 < ratio < 1.01      # measured: 0.99995, 0.9985 (with S4F_RESID=bf16: 0.9987)
 
 
 @pytest.mark.parametrize('which', [0, 1])

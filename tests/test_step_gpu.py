@@ -137,6 +137,28 @@ def test_step_vs_golden(name, dtype):
     assert not msgs, '\n'.join(msgs[:20])
 
 
+def test_step_with_the_bf16_residual_stream(monkeypatch):
+    """opt-in S4F_RESID=bf16 (runtime.set_residual_fp32(False)): token tensors between the layers and their gradients in bf16.
+    Not the default - at DeiT-B size the gradient arena's cosine against the fp32 step falls from 0.99995 to 0.9987 for 0.24 ms
+    of the step - but the path (typed LayerNorm, bf16 residual GEMM epilogues, typed token assembly) stays held to the golden."""
+    from s4former_amd import runtime
+    z, meta = load_gold('mt_pasa')
+    runtime.set_residual_fp32(False)
+    try:
+        model, opt, sched = build_product(meta, 'bf16')
+        rec = run_product(model, opt, sched, meta, iters=1)
+    finally:
+        runtime.set_residual_fp32(True)
+    msgs = []
+    for k, v in zip([str(k) for k in z['it0_loss_keys']], z['it0_loss_vals']):
+        if 'loss' in k:
+            assert abs(rec[0]['log'][k] - v) <= 5e-3 * abs(v), (k, rec[0]['log'][k], v)
+    for k, v in zip([str(k) for k in z['it0_gn_keys']], z['it0_gn_vals']):
+        assert abs(rec[0]['gn'][k] - v) <= 8e-2 * (abs(v) + 1e-12), (k, rec[0]['gn'][k], v)
+    C.check_grad_samples(z, 0, _SampleView(rec[0]['g']), 3e-1, msgs, rec='tiny/mt_pasa/bf16/resid_bf16', mtol=0.12)
+    assert not msgs, '\n'.join(msgs)
+
+
 LOGIT_TOL = 2e-5     # stated bound on the fp32-mode teacher logits' deviation, relative to max |logit|
 
 
