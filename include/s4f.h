@@ -288,6 +288,14 @@ int s4f_confusion_counts(const uint8_t* pred, const uint8_t* label, int64_t n, i
 int s4f_input_view(const uint8_t* img, const uint8_t* seg, float* out_img, uint8_t* out_seg, int H, int W, int OH, int OW,
                    const int* crop, int flip, const float* photo, const float* mean, const float* std, int to_rgb, float pad_val,
                    int seg_pad_val, s4f_stream stream);
+/* The same with the multi-scale Resize of the training pipelines in front (transforms.py:171-427, configs/setr/..._MT.py:37,112:
+ * Resize(img_scale=(2048, 512), ratio_range=(0.5, 2.0)) -> mmcv.imrescale -> cv2.resize): the crop window `crop` lives in the
+ * resized image of RH x RW pixels, which is never materialised - every output pixel interpolates its source pixels on the fly
+ * (image: cv2.INTER_LINEAR's 8-bit fixed-point rule incl. the 2 x 2 area case at an exact factor 2; segmentation map:
+ * cv2.INTER_NEAREST).  RH == H and RW == W: s4f_input_view.  The scale is drawn on the host (pipeline.draw_resize). */
+int s4f_input_view_resized(const uint8_t* img, const uint8_t* seg, float* out_img, uint8_t* out_seg, int H, int W, int RH, int RW,
+                           int OH, int OW, const int* crop, int flip, const float* photo, const float* mean, const float* std,
+                           int to_rgb, float pad_val, int seg_pad_val, s4f_stream stream);
 
 /* Stand-alone CrossEntropyLoss on NCHW / [N,C] fp32 logits (cross_entropy_loss.py:12-63): per-element loss
  * (0 where ignored), optional class weights; spatial = H*W (1 for [N,C]). */

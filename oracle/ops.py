@@ -352,16 +352,84 @@ def photometric(img, p):
     return img
 
 
-def input_view(img, seg, bbox, flip, p, crop_size, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True):
-    """RandomCrop.crop -> RandomFlip (horizontal) -> PhotoMetricDistortion -> Normalize -> Pad -> CHW
-    (transforms.py:826-832, 450-481, 1241-1268, 589-611, 541-569).  -> (img fp32 [3, ch, cw], seg uint8 [ch, cw])"""
+def rescale_size(old_wh, scale):
+    """mmcv.image.geometric.rescale_size (mmcv-full 1.4.4 - 1.6.0, absent here: restated): (w, h), scale = factor or
+    (edge, edge) -> (new_w, new_h) = int(x * factor + 0.5), factor = min(long / max(h, w), short / min(h, w))"""
+    w, h = old_wh
+    if isinstance(scale, (float, int)):
+        factor = scale
+    else:
+        factor = min(max(scale) / max(h, w), min(scale) / min(h, w))
+    return int(w * float(factor) + 0.5), int(h * float(factor) + 0.5)
+
+
+def cv_resize_linear_u8(img, new_hw):
+    """cv2.resize(img, (new_w, new_h), interpolation=cv2.INTER_LINEAR) on uint8 [H, W, C] (what mmcv.imrescale calls for the
+    image, transforms.py:370).  cv2 is absent: OpenCV's published 8-bit algorithm restated (imgproc/resize.cpp: coordinates
+    (d + 0.5) * scale - 0.5 in float, weights rounded to 1 / 2048 as shorts, horizontal pass in int32, vertical pass
+    (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2; an exact factor-2 shrink is the 2 x 2 area mean).
+    PARITY UNPINNED: kernel and this restatement agree bit for bit, neither has met cv2."""
     import numpy as np
+    H, W = img.shape[:2]
+    RH, RW = int(new_hw[0]), int(new_hw[1])
+    if (RH, RW) == (H, W):
+        return img.copy()
+    if RW * 2 == W and RH * 2 == H:
+        a = img.astype(np.int32)
+        return ((a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    scale_x, scale_y = 1.0 / (RW / W), 1.0 / (RH / H)
+
+    def axis(n_dst, n_src, scale, clamp_weight):
+        f = ((np.arange(n_dst) + 0.5) * scale - 0.5).astype(np.float32)
+        s0 = np.floor(f).astype(np.int64)
+        f = (f - s0.astype(np.float32)).astype(np.float32)
+        if clamp_weight:                              # horizontal: fx = 0 where the pair would leave the row
+            lo, hi = s0 < 0, s0 >= n_src - 1
+            f = np.where(lo | hi, np.float32(0), f)
+            s0 = np.where(lo, 0, np.where(hi, n_src - 1, s0))
+        w0 = np.clip(np.rint((np.float32(1) - f) * np.float32(2048)), -32768, 32767).astype(np.int32)
+        w1 = np.clip(np.rint(f * np.float32(2048)), -32768, 32767).astype(np.int32)
+        i0 = np.clip(s0, 0, n_src - 1)
+        i1 = np.clip(s0 + 1, 0, n_src - 1)
+        return i0, i1, w0, w1
+    x0, x1, a0, a1 = axis(RW, W, scale_x, True)
+    y0, y1, b0, b1 = axis(RH, H, scale_y, False)
+    src = img.astype(np.int32)
+    rows = src[:, x0] * a0[None, :, None] + src[:, x1] * a1[None, :, None]            # [H, RW, C]
+    r0, r1 = rows[y0], rows[y1]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def cv_resize_nearest(seg, new_hw):
+    """cv2.resize(seg, (new_w, new_h), interpolation=cv2.INTER_NEAREST) (mmcv.imrescale(..., 'nearest'), transforms.py:393):
+    source index min(floor(d * scale), size - 1) with scale = 1. / (dst / src) in double.  PARITY UNPINNED (cv2 absent)."""
+    import numpy as np
+    H, W = seg.shape[:2]
+    RH, RW = int(new_hw[0]), int(new_hw[1])
+    sy = np.minimum(np.floor(np.arange(RH) * (1.0 / (RH / H))).astype(np.int64), H - 1)
+    sx = np.minimum(np.floor(np.arange(RW) * (1.0 / (RW / W))).astype(np.int64), W - 1)
+    return seg[sy][:, sx]
+
+
+def input_view(img, seg, bbox, flip, p, crop_size, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), to_rgb=True,
+               resize_to=None, flip_direction='horizontal'):
+    """[Resize ->] RandomCrop.crop -> RandomFlip -> PhotoMetricDistortion -> Normalize -> Pad -> CHW
+    (transforms.py:171-427, 826-832, 450-481, 1241-1268, 589-611, 541-569).  -> (img fp32 [3, ch, cw], seg uint8 [ch, cw])"""
+    import numpy as np
+    if resize_to is not None:
+        img = cv_resize_linear_u8(img, resize_to)
+        seg = cv_resize_nearest(seg, resize_to) if seg is not None else None
     y1, y2, x1, x2 = bbox
     img = img[y1:y2, x1:x2]
     seg = seg[y1:y2, x1:x2] if seg is not None else None
     if flip:
-        img = img[:, ::-1]
-        seg = seg[:, ::-1] if seg is not None else None
+        if flip_direction == 'horizontal':
+            img = img[:, ::-1]
+            seg = seg[:, ::-1] if seg is not None else None
+        else:
+            img = img[::-1]
+            seg = seg[::-1] if seg is not None else None
     img = photometric(np.ascontiguousarray(img), p).astype(np.float32)
     if to_rgb:
         img = img[..., ::-1]

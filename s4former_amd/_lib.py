@@ -88,6 +88,8 @@ _SIGS = {
     's4f_confusion_counts': [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p],
     's4f_input_view': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), c_int, POINTER(c_float),
                        POINTER(c_float), POINTER(c_float), c_int, c_float, c_int, c_void_p],
+    's4f_input_view_resized': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), c_int,
+                               POINTER(c_float), POINTER(c_float), POINTER(c_float), c_int, c_float, c_int, c_void_p],
     's4f_ce_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p],
     's4f_ce_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p],
     's4f_ema': [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p],

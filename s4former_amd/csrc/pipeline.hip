@@ -1,4 +1,5 @@
-// Device half of the training input pipeline: everything the reference's pipeline does AFTER decode + Resize
+// Device half of the training input pipeline: everything the reference's pipeline does AFTER decode (round 3:
+// Resize included - the crop window is cut out of a VIRTUAL resized image whose pixels are interpolated on the fly)
 // (configs/setr/*:41-118; mmseg/datasets/pipelines/transforms.py): RandomCrop window, RandomFlip, PhotoMetricDistortion,
 // Normalize (BGR -> RGB, mean / std), Pad to the crop size, HWC uint8 -> CHW fp32 - ONE pass over the pixels per view instead
 // of six numpy / cv2 passes per view on the data-loader workers.  The random DECISIONS stay on the host (pipeline.py draws them
@@ -21,7 +22,10 @@ struct PipeArgs {
   float* out_img;          // [3, OH, OW]
   uint8_t* out_seg;        // [OH, OW] or null
   int H, W, OH, OW;
-  int cy, cx, ch, cw;      // crop window (clipped to the image by the host)
+  int RH, RW;              // size of the (virtual) resized image the crop window lives in; == H, W: no Resize
+  double scale_x, scale_y; // cv::resize: 1. / ((double)RW / W), 1. / ((double)RH / H)
+  int area2;               // cv::resize turns INTER_LINEAR into the 2 x 2 area average when both scales are exactly 2
+  int cy, cx, ch, cw;      // crop window in the resized image (clipped to it by the host)
   int flip;                // 0 none, 1 horizontal, 2 vertical (applied to the cropped window)
   int bright_on, contrast_on, contrast_first, sat_on, hue_on, hue_delta;
   float bright_delta, contrast_alpha, sat_alpha;
@@ -87,6 +91,61 @@ __device__ __forceinline__ void hsv2bgr_u8(int hi, int si, int vi, int& b, int& 
   r = sat_u8_round(fr * 255.f);
 }
 
+// ---- Resize (transforms.py:171-427 -> mmcv.imrescale -> cv2.resize): the pixel (ry, rx) of the resized image, computed from
+// the source on the fly - only the pixels of the crop window are ever produced.
+// Image: cv2.INTER_LINEAR on 8-bit data = OpenCV's fixed-point scheme (imgproc resize.cpp: HResizeLinear / VResizeLinear<uchar,
+// int, short>, INTER_RESIZE_COEF_BITS = 11): source coordinate (d + 0.5) * scale - 0.5 in float, weights rounded to 1 / 2048,
+// horizontal pass in 32-bit integers, vertical pass ((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2.
+// Segmentation map: cv2.INTER_NEAREST = min(floor(d * scale), size - 1).
+__device__ __forceinline__ int sat_short_round(float x) {
+  const int i = (int)rintf(x);
+  return i < -32768 ? -32768 : (i > 32767 ? 32767 : i);
+}
+
+__device__ __forceinline__ void resized_pixel(const PipeArgs& a, int ry, int rx, int& b, int& g, int& r) {
+  if (a.RH == a.H && a.RW == a.W) {
+    const uint8_t* p = a.img + ((long)ry * a.W + rx) * 3;
+    b = p[0]; g = p[1]; r = p[2];
+    return;
+  }
+  if (a.area2) {
+    const uint8_t* p = a.img + ((long)(2 * ry) * a.W + 2 * rx) * 3;
+    const uint8_t* q = p + (long)a.W * 3;
+    b = (p[0] + p[3] + q[0] + q[3] + 2) >> 2;
+    g = (p[1] + p[4] + q[1] + q[4] + 2) >> 2;
+    r = (p[2] + p[5] + q[2] + q[5] + 2) >> 2;
+    return;
+  }
+  float fx = (float)((rx + 0.5) * a.scale_x - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= (float)sx;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= a.W - 1) { fx = 0.f; sx = a.W - 1; }
+  const int a0 = sat_short_round((1.f - fx) * 2048.f), a1 = sat_short_round(fx * 2048.f);
+  float fy = (float)((ry + 0.5) * a.scale_y - 0.5);
+  const int sy = (int)floorf(fy);
+  fy -= (float)sy;
+  const int b0 = sat_short_round((1.f - fy) * 2048.f), b1 = sat_short_round(fy * 2048.f);
+  const int y0 = min(max(sy, 0), a.H - 1), y1 = min(max(sy + 1, 0), a.H - 1), x1 = min(sx + 1, a.W - 1);
+  const uint8_t* p00 = a.img + ((long)y0 * a.W + sx) * 3;
+  const uint8_t* p01 = a.img + ((long)y0 * a.W + x1) * 3;
+  const uint8_t* p10 = a.img + ((long)y1 * a.W + sx) * 3;
+  const uint8_t* p11 = a.img + ((long)y1 * a.W + x1) * 3;
+  int out[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int r0 = p00[c] * a0 + p01[c] * a1, r1 = p10[c] * a0 + p11[c] * a1;
+    out[c] = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+  }
+  b = out[0]; g = out[1]; r = out[2];
+}
+
+__device__ __forceinline__ int resized_seg(const PipeArgs& a, int ry, int rx) {
+  if (a.RH == a.H && a.RW == a.W) return a.seg[(long)ry * a.W + rx];
+  const int sy = min((int)floor(ry * a.scale_y), a.H - 1), sx = min((int)floor(rx * a.scale_x), a.W - 1);
+  return a.seg[(long)sy * a.W + sx];
+}
+
 __global__ __launch_bounds__(256) void input_view_kernel(const PipeArgs a) {
   const long total = (long)a.OH * a.OW;
   const long stride = (long)gridDim.x * blockDim.x;
@@ -98,8 +157,8 @@ __global__ __launch_bounds__(256) void input_view_kernel(const PipeArgs a) {
     if (inside) {
       const int sy = a.cy + (a.flip == 2 ? a.ch - 1 - oy : oy);
       const int sx = a.cx + (a.flip == 1 ? a.cw - 1 - ox : ox);
-      const uint8_t* p = a.img + ((long)sy * a.W + sx) * 3;
-      int b = p[0], g = p[1], r = p[2];
+      int b, g, r;
+      resized_pixel(a, sy, sx, b, g, r);
       if (a.bright_on) {
         b = conv_u8((float)b + a.bright_delta); g = conv_u8((float)g + a.bright_delta); r = conv_u8((float)r + a.bright_delta);
       }
@@ -126,7 +185,7 @@ __global__ __launch_bounds__(256) void input_view_kernel(const PipeArgs a) {
       o0 = (c0 - a.mean[0]) * a.stdinv[0];
       o1 = (c1 - a.mean[1]) * a.stdinv[1];
       o2 = (c2 - a.mean[2]) * a.stdinv[2];
-      if (a.seg) segv = a.seg[(long)sy * a.W + sx];
+      if (a.seg) segv = resized_seg(a, sy, sx);
     }
     a.out_img[i] = o0;
     a.out_img[total + i] = o1;
@@ -137,18 +196,23 @@ __global__ __launch_bounds__(256) void input_view_kernel(const PipeArgs a) {
 
 }  // namespace
 
-S4F_API int s4f_input_view(const uint8_t* img, const uint8_t* seg, float* out_img, uint8_t* out_seg, int H, int W, int OH, int OW,
-                           const int* crop, int flip, const float* photo, const float* mean, const float* std, int to_rgb,
-                           float pad_val, int seg_pad_val, s4f_stream stream) {
+S4F_API int s4f_input_view_resized(const uint8_t* img, const uint8_t* seg, float* out_img, uint8_t* out_seg, int H, int W, int RH,
+                                   int RW, int OH, int OW, const int* crop, int flip, const float* photo, const float* mean,
+                                   const float* std, int to_rgb, float pad_val, int seg_pad_val, s4f_stream stream) {
   S4F_CHECK(img && out_img && crop && photo && mean && std, "s4f_input_view: null pointer");
-  S4F_CHECK(H > 0 && W > 0 && OH > 0 && OW > 0 && flip >= 0 && flip <= 2, "s4f_input_view: bad geometry");
+  S4F_CHECK(H > 0 && W > 0 && RH > 0 && RW > 0 && OH > 0 && OW > 0 && flip >= 0 && flip <= 2, "s4f_input_view: bad geometry");
   PipeArgs a;
   a.img = img; a.seg = seg; a.out_img = out_img; a.out_seg = out_seg;
-  a.H = H; a.W = W; a.OH = OH; a.OW = OW;
+  a.H = H; a.W = W; a.OH = OH; a.OW = OW; a.RH = RH; a.RW = RW;
+  {
+    const double inv_x = (double)RW / W, inv_y = (double)RH / H;      // cv::resize(): inv_scale, scale = 1. / inv_scale
+    a.scale_x = 1. / inv_x; a.scale_y = 1. / inv_y;
+    a.area2 = (RW * 2 == W && RH * 2 == H) ? 1 : 0;
+  }
   a.cy = crop[0]; a.cx = crop[1]; a.ch = crop[2]; a.cw = crop[3];
-  S4F_CHECK(a.cy >= 0 && a.cx >= 0 && a.ch > 0 && a.cw > 0 && a.cy + a.ch <= H && a.cx + a.cw <= W && a.ch <= OH && a.cw <= OW,
+  S4F_CHECK(a.cy >= 0 && a.cx >= 0 && a.ch > 0 && a.cw > 0 && a.cy + a.ch <= RH && a.cx + a.cw <= RW && a.ch <= OH && a.cw <= OW,
             "s4f_input_view: crop window (%d, %d, %d, %d) outside the %dx%d image or larger than the %dx%d output", a.cy, a.cx,
-            a.ch, a.cw, H, W, OH, OW);
+            a.ch, a.cw, RH, RW, OH, OW);
   a.flip = flip;
   // photo = [bright_on, bright_delta, contrast_on, contrast_alpha, contrast_first, sat_on, sat_alpha, hue_on, hue_delta]
   a.bright_on = photo[0] != 0.f; a.bright_delta = photo[1];
@@ -166,4 +230,11 @@ S4F_API int s4f_input_view(const uint8_t* img, const uint8_t* seg, float* out_im
   hipLaunchKernelGGL(input_view_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, a);
   S4F_LAUNCH_CHECK();
   return 0;
+}
+
+S4F_API int s4f_input_view(const uint8_t* img, const uint8_t* seg, float* out_img, uint8_t* out_seg, int H, int W, int OH, int OW,
+                           const int* crop, int flip, const float* photo, const float* mean, const float* std, int to_rgb,
+                           float pad_val, int seg_pad_val, s4f_stream stream) {
+  return s4f_input_view_resized(img, seg, out_img, out_seg, H, W, H, W, OH, OW, crop, flip, photo, mean, std, to_rgb, pad_val,
+                                seg_pad_val, stream);
 }

@@ -262,3 +262,32 @@ WHOLE_CASE = dict(img_shape=(60, 56), ori_shape=(83, 71), seed_x=77)      # with
 def slide_input():
     g = torch.Generator().manual_seed(SLIDE_CASE['seed_x'])
     return torch.randn(2, 3, 96, 112, generator=g).clamp_(-2.2, 2.7)
+
+
+# ------------------------------------------------------------------------------------------------ input pipeline fixtures
+IMG_NORM = dict(mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375))      # configs/setr/*:9-10
+
+# name: the reference's train / unsup_train pipeline (configs/setr/..._MT.py:34-118) on a seeded sample; numpy seeded with seed + 1000
+PIPELINE_CASES = {
+    'sup_a': dict(tag='sup', seed=1, hw=(70, 90), crop=(64, 64), img_scale=(200, 100), ratio_range=(0.5, 2.0)),
+    'sup_b': dict(tag='sup', seed=2, hw=(96, 64), crop=(64, 64), img_scale=(160, 96), ratio_range=(0.5, 2.0)),
+    'sup_small': dict(tag='sup', seed=3, hw=(60, 80), crop=(64, 64), img_scale=(100, 50), ratio_range=(0.5, 1.0)),   # resized image smaller than the crop: Pad fills
+    'sup_c': dict(tag='sup', seed=4, hw=(50, 130), crop=(48, 80), img_scale=(260, 100), ratio_range=(0.5, 2.0)),
+    'unsup_a': dict(tag='unsup', seed=5, hw=(70, 90), crop=(64, 64), img_scale=(200, 100), ratio_range=(0.5, 2.0)),
+    'unsup_b': dict(tag='unsup', seed=6, hw=(128, 100), crop=(64, 64), img_scale=(256, 128), ratio_range=(0.5, 2.0)),
+    'unsup_c': dict(tag='unsup', seed=7, hw=(81, 121), crop=(64, 64), img_scale=(242, 81), ratio_range=(0.9, 1.1)),
+    'unsup_d': dict(tag='unsup', seed=8, hw=(64, 64), crop=(64, 64), img_scale=(128, 128), ratio_range=(0.5, 2.0)),
+}
+
+
+def pipeline_sample(seed, h, w):
+    """uint8 BGR image with smooth structure (so that interpolation matters) + label blocks with an ignore band"""
+    g = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(yy * 3 + xx * 2) % 256, (yy * 5 + 40) % 256, (xx * 7 + yy) % 256], -1).astype(np.int64)
+    img = np.clip(base + g.randint(-20, 21, size=(h, w, 3)), 0, 255).astype(np.uint8)
+    img[:4, :4] = 0
+    img[4:8, :4] = 255
+    seg = (g.randint(0, 21, size=((h + 15) // 16, (w + 15) // 16)).repeat(16, 0).repeat(16, 1)[:h, :w]).astype(np.uint8)
+    seg[::11] = 255
+    return img, seg
