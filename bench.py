@@ -219,6 +219,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    launches0 = getattr(reducer, 'launches', 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(it)
@@ -228,6 +229,7 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    grad_collectives = (getattr(reducer, 'launches', 0) - launches0) / max(1, args.steps)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -314,7 +316,9 @@ def main():
                                 crop=f'{img}x{img}', classes=ncls, parallelism=f'dp{world}', weights='random-init DeiT-B',
                                 teacher_conv_seg_gain=round(seg_gain, 2),
                                 dist_backend=dist.get_backend() if world > 1 else None,
-                                ranks_seen=dist.get_world_size() if world > 1 else 1),
+                                ranks_seen=dist.get_world_size() if world > 1 else 1,
+                                grad_collectives_per_step=round(grad_collectives, 2) if grad_collectives else None,
+                                stream_layout_check=getattr(reducer, 'stream_layout', None)),
                     roofline=roofline, cpu_baseline=cpu, losses=losses, mask_ratio=mask_ratio,
                     host_enqueue_ms_per_step=round(1e3 * host_dt / args.steps, 3),
                     host_enqueue_idle_queue_ms=round(host_idle_ms, 3))

@@ -63,6 +63,8 @@ class GradReducer:
         self._handles = []
         self._done = []          # ranges already launched in this step
         self._store = None
+        self.stream_layout = None    # result of functional.check_stream_layout (N > 1 on GPUs)
+        self.launches = 0            # collectives issued so far (bench.py reports the per-step count)
 
     def attach(self, store):
         self._store = store
@@ -96,6 +98,7 @@ class GradReducer:
     def _launch(self, t):
         with self._comm_ctx(t):
             self._handles.append(self.issue(t))
+        self.launches += 1
 
     def _range_done(self, a, b):
         if not collectives_active() or self._store is None or self._store.grad is None:
@@ -158,13 +161,23 @@ def setup_data_parallel(model, optimizer, device, reducer=None):
     if model.teacher_store is not None:
         model.teacher_store.mark_dirty()
     reducer.attach(model.student_store)
+    if collectives_active():
+        # three encoder layers (3 x 7.09 M fp32 = 85 MB) per gradient bucket: 4 all-reduces for the backbone during backward
+        # + the rest (heads, patch embedding) in 128 MB buckets at the end, instead of one collective per layer and head (41)
+        model.student_store.coalesce_min = int(os.environ.get('S4F_BUCKET_MIN_ELEMS', str(20_000_000)))
     if collectives_active() and os.environ.get('S4F_STREAM_LAYOUT', '1') != '0' and torch.device(device).type == 'cuda':
         # ON by default since round 2: measured through RCCL itself (one-rank group, tools/exp/rccl_world1.py) the step costs
         # 33.95 ms with the streams bound to hardware queues in whatever order they are first used and 32.58 ms with this
         # order (30.75 ms without any process group).  It changes which streams share a queue, never what runs or in which
         # order the collectives are issued.
-        from .functional import lay_out_streams
-        reducer._stream = lay_out_streams(device)      # collectives + eager SGD issue from the weight-gradient stream
+        from .functional import lay_out_streams, check_stream_layout
+        side = lay_out_streams(device)
+        # the layout rests on the runtime binding streams to its hardware queues in first-use order (undocumented): verify the
+        # property it is meant to give - the chain, the two head streams and the weight-gradient stream do not serialise each
+        # other - with two concurrent spin kernels per pair, and fall back to a communication stream of its own otherwise
+        reducer.stream_layout = check_stream_layout(device)
+        if reducer.stream_layout.get('ok', False):
+            reducer._stream = side                     # collectives + eager SGD issue from the weight-gradient stream
     if os.environ.get('S4F_EAGER_SGD', '1') != '0':
         # parameter ranges are updated as soon as their (all-reduced) gradient is final, behind the rest of backward
         optimizer.attach_eager(model.student_store, reducer if collectives_active() else None, reducer.grad_scale())

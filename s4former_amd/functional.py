@@ -85,6 +85,46 @@ def lay_out_streams(device):
 _burn = []
 
 
+def check_stream_layout(device, cycles=400_000):
+    """Do the chain's stream, the two head streams and the weight-gradient stream run CONCURRENTLY (= sit on different hardware
+    queues)?  Two single-thread spin kernels (torch.cuda._sleep) started together on a pair of streams take about one spin if
+    the streams are on different queues and two if they share one.  Returns dict(ok=bool, pairs={name: ratio}); ok = every
+    pair overlapped (ratio < 1.5).  A few hundred microseconds, once, at set-up."""
+    res = dict(ok=False, pairs={})
+    try:
+        names = [('main', torch.cuda.current_stream(device)), ('decode', head_stream(device, 'decode')), ('aux', head_stream(device, 'aux')),
+                 ('side', side_stream(device))]
+
+        def timed(streams):
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            cur = torch.cuda.current_stream(device)
+            e0.record(cur)
+            for st in streams:
+                st.wait_event(e0) if st != cur else None
+                with torch.cuda.stream(st):
+                    torch.cuda._sleep(cycles)
+            for st in streams:
+                if st != cur:
+                    cur.wait_stream(st)
+            e1.record(cur)
+            torch.cuda.synchronize(device)
+            return e0.elapsed_time(e1)
+        timed([names[0][1]])                                  # warm-up
+        one = min(timed([names[0][1]]) for _ in range(3))
+        ok = True
+        for i in range(len(names)):
+            for j in range(i + 1, len(names)):
+                t = min(timed([names[i][1], names[j][1]]) for _ in range(2))
+                r = t / max(one, 1e-6)
+                res['pairs'][f'{names[i][0]}+{names[j][0]}'] = round(r, 2)
+                ok = ok and r < 1.5
+        res['ok'] = ok
+    except Exception as e:                                    # noqa: BLE001 - a missing _sleep or an odd runtime: no claim, fall back
+        res['error'] = f'{type(e).__name__}: {e}'
+    return res
+
+
 def extra_streams(device=None):
     """every stream besides the caller's that this package launches compute kernels on"""
     idx = None if device is None else torch.device(device).index

@@ -42,6 +42,25 @@ def _worker(rank, world, port, q):
     red2.reduce_(st.grad)
     red2.wait()
     res['grad2'] = (st.grad * red2.grad_scale()).clone()
+    # 1c. coalesced buckets (ParamStore.range_done with coalesce_min): layer ranges reported one by one in backward order are
+    # handed to the reducer three at a time; what stays below the size is covered by reduce_()
+    from s4former_amd.params import ParamStore
+    ps = ParamStore.__new__(ParamStore)
+    ps.group_ranges = {'backbone': dict(params=(0, 240_000), all=(0, 240_000)), 'head': dict(params=(240_000, 300_032), all=(240_000, 300_032))}
+    ps.grad = torch.randn(300_032, generator=torch.Generator().manual_seed(300 + rank))
+    ps.coalesce_min, ps.step_epoch = 60_000, 1
+    red3 = GradReducer(bucket_mb=0.25, side_stream=False).attach(ps)
+    launched = []
+    issue0 = GradReducer.issue
+    red3.issue = lambda t: (launched.append(t.numel()), issue0(t))[1]
+    ps.range_done(240_000, 270_016)                    # a head: below the size, own group
+    for k in range(11, -1, -1):                         # twelve "layers" of 20,000 elements, last first
+        ps.range_done(k * 20_000, (k + 1) * 20_000)
+    early = list(launched)
+    red3.reduce_(ps.grad)
+    red3.wait()
+    res['grad3'] = (ps.grad * red3.grad_scale()).clone()
+    res['buckets3'] = (early, list(launched))
     # 2. parameters broadcast from rank 0
     p = torch.full((1000,), float(rank))
     red.broadcast_(p, src=0)
@@ -88,6 +107,12 @@ def test_world2_gloo():
     h0 = torch.randn(300_001, generator=torch.Generator().manual_seed(200))
     h1 = torch.randn(300_001, generator=torch.Generator().manual_seed(201))
     assert torch.allclose(out[0]['grad2'], (h0 + h1) / 2, atol=1e-6) and torch.equal(out[0]['grad2'], out[1]['grad2'])
+    k0 = torch.randn(300_032, generator=torch.Generator().manual_seed(300))
+    k1 = torch.randn(300_032, generator=torch.Generator().manual_seed(301))
+    assert torch.allclose(out[0]['grad3'], (k0 + k1) / 2, atol=1e-6) and torch.equal(out[0]['grad3'], out[1]['grad3'])
+    early, all_ = out[0]['buckets3']
+    assert early == [60_000] * 4, early                   # 12 layers -> 4 buckets of 3 during "backward", nothing for the small head
+    assert sum(all_) == 300_032 and len(all_) <= 6, all_  # every element exactly once, the rest in one more bucket
     assert out[0]['bcast'] == 0.0 and out[1]['bcast'] == 0.0
     # local loss stays local (it is what backward runs on); logged values are the rank mean
     assert out[0]['loss_local'] == 1.5 and out[1]['loss_local'] == 3.0

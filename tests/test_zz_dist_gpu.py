@@ -162,8 +162,8 @@ def test_one_rank_rccl_group_runs_the_data_path(single, tmp_path):
     result must equal the plain single-process run (all-reduce over one rank is the identity), and the gradient ranges and
     SyncBN exchanges must really have been issued.  Skipped (not failed) when RCCL cannot initialise on the box."""
     d = str(tmp_path)
-    env = _env()
-    env.pop('S4F_DIST_BACKEND')
+    env = _env(S4F_BUCKET_MIN_ELEMS='1')          # every final range goes out at once: the overlapped per-range path (the tiny
+    env.pop('S4F_DIST_BACKEND')                   # model's layers are far below the production bucket size of three DeiT-B layers)
     try:
         r = subprocess.run([sys.executable, WORKER, '--out', d, '--flags', 'plain', '--rccl-one-rank'], cwd=ROOT, env=env,
                            capture_output=True, text=True, timeout=CAP)
