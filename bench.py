@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
+    ap.add_argument('--windows', type=int, default=3, help='timed windows of --steps steps each; the median window is reported')
     ap.add_argument('--timeline', default='', help='write the HIP-event timeline of the profiled step (no tracer attached) to this JSON file')
     ap.add_argument('--mask-ratio', type=float, default=0.5,
                     help='target fraction of confident teacher pixels: the randomly initialised teacher conv_seg is '
@@ -220,20 +221,30 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     launches0 = getattr(reducer, 'launches', 0)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(it)
-        it += 1
-    host_dt = time.perf_counter() - t0             # time the host needed to enqueue the K steps (no sync inside)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    grad_collectives = (getattr(reducer, 'launches', 0) - launches0) / max(1, args.steps)
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax)
+    # The timed region: EXACTLY K steps between a barrier + device synchronise on both sides, as the contract says - taken
+    # `--windows` times back to back (default 3: three windows of 20 steps are < 2 s); `value` is the MEDIAN window, the spread
+    # across the windows is reported beside it (a single 0.6 s window moved by +-1 % between runs of one binary).
+    win_dt, win_host = [], []
+    for _ in range(max(1, args.windows)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step(it)
+            it += 1
+        win_host.append(time.perf_counter() - t0)  # time the host needed to enqueue the K steps (no sync inside)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        wdt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(wdt, op=dist.ReduceOp.MAX)
+        win_dt.append(float(wdt))
+    order = sorted(range(len(win_dt)), key=lambda i: win_dt[i])
+    mid = order[len(order) // 2]
+    dt, host_dt = win_dt[mid], win_host[mid]
+    grad_collectives = (getattr(reducer, 'launches', 0) - launches0) / max(1, args.steps * len(win_dt))
     losses = {k: float(v) for k, v in out['log_vars'].items()}
     mask_ratio = float(model.last_mask_ratio) if model.last_mask_ratio is not None else None
 
@@ -290,14 +301,24 @@ def main():
         import glob
         tfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_gemm_hbm_traffic.json')))     # the latest round's passes
         tpath = tfiles[-1] if tfiles else ''
+        traffic_note = None
         if args.workload == 'semi' and args.dtype == 'bf16' and tpath:
             # HBM bytes per GEMM launch from the rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command
-            # (separate --pmc runs, FETCH_SIZE doubled for gfx950); bench.py cannot run the profiler on itself.
-            traffic = round(json.load(open(tpath))['hbm_bytes_per_launch'])
+            # (separate --pmc runs, FETCH_SIZE doubled for gfx950); bench.py cannot run the profiler on itself.  The file names
+            # the kernel sources it was measured on: a profile that predates a kernel change is NOT reported.
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from pmc_traffic import kernel_src_sha
+            tj = json.load(open(tpath))
+            if tj.get('kernel_src_sha') == kernel_src_sha():
+                traffic = round(tj['hbm_bytes_per_launch'])
+            else:
+                traffic_note = (f'{os.path.basename(tpath)} was measured on other GEMM kernel sources (sha {tj.get("kernel_src_sha")} '
+                                f'vs {kernel_src_sha()}): re-run tools/profile_round.sh; traffic not reported')
+                print('bench.py: STALE TRAFFIC PROFILE - ' + traffic_note, file=sys.stderr, flush=True)
         roofline = dict(bound='mfma', kernel='s4f_gemm family: g2::gemm2_kernel / g5::gemm5_kernel / g6::gemm6_kernel (dense + implicit-GEMM conv, all launches of a step)',
                         achieved=round(gemm_gflop / gemm_ms, 1), peak=peak, unit='TFLOP/s',
                         frac=round(gemm_gflop / gemm_ms / peak, 4), traffic=traffic,
-                        traffic_source=('profiles/' + os.path.basename(tpath)) if traffic is not None else None,
+                        traffic_source=('profiles/' + os.path.basename(tpath)) if traffic is not None else traffic_note,
                         algorithmic_gflop_per_launch=round(gemm_gflop / gemm_calls, 2),
                         launches_per_step=gemm_calls, avg_launch_ms=round(gemm_ms / gemm_calls, 4),
                         share_of_step_kernel_time=round(gemm_ms / total_ms, 3),
@@ -311,6 +332,7 @@ def main():
     if rank == 0:
         line = dict(metric='train images/sec DeiT-B 512x512 S4Former step', value=round(ips, 3), unit='images/s',
                     n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * dt / args.steps, 3),
+                    ms_per_step_windows=[round(1e3 * w / args.steps, 3) for w in win_dt],
                     higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
                     config=dict(workload=f'{args.workload}: {desc}', images_per_step_per_gpu=n_sup + n_unsup,
                                 crop=f'{img}x{img}', classes=ncls, parallelism=f'dp{world}', weights='random-init DeiT-B',
