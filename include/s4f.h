@@ -169,6 +169,45 @@ int s4f_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const 
                       void* dqkv, const float* bias_u, const float* row_flag, float bias_w, int B, int N, int H,
                       int dtype, s4f_stream stream);
 
+/* ------------------------------------------------------------------------------------------- encoder layer (round 3)
+ * TransformerEncoderLayer.forward (vit.py:113-127: LN -> MultiheadAttention -> +x; LN -> FFN(GELU) -> +x) and its backward as ONE
+ * call each: the fixed launch sequence of a layer is issued by the library from this descriptor instead of one host call per
+ * kernel (LN, qkv GEMM, attention, proj GEMM + residual, LN, fc1 GEMM + GELU, fc2 GEMM + residual | colsum, fc2 dgrad x gelu',
+ * fc1 dgrad, LN backward, proj dgrad, attention backward, grouped weight gradients + in_proj bias sums, qkv dgrad, LN backward).
+ * All pointers are device pointers owned by the caller; T = dtype, X = xdtype (residual stream).  hint[]: tile_hint of the
+ * GEMMs {qkv, proj, fc1, fc2, fc2 dgrad, fc1 dgrad, proj dgrad, qkv dgrad} (0 = automatic); wg_hint / wg_splitk: the grouped
+ * weight-gradient launch. */
+typedef struct s4f_layer_desc {
+  int32_t B, N, E, F, H;                 /* images, tokens per image, embed dims (= 64 H), FFN channels, heads */
+  int32_t dtype, xdtype;
+  float eps, bias_w;
+  int32_t hint[8];
+  int32_t wg_hint, wg_splitk, fold_colsum, reserved0;
+  /* parameters: fp32 masters, operand-typed shadows [out][in], transposed shadows [in][out] (bf16 backward; NULL in fp32) */
+  const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bo, *b1, *b2;
+  const void *wqkv, *wo, *w1, *w2;
+  const void *wqkv_T, *wo_T, *w1_T, *w2_T;
+  /* PASA rank-1 attention bias (vit.py:519-535) or NULL */
+  const float *bias_u, *row_flag;
+  /* forward: x X [B,N,E] in; saved for the backward: xn T, mean1 / rstd1 fp32 [B N], qkv T [B,N,3E], ctx T, lse fp32 [B,H,N],
+   * x1 X, xn2 T, mean2 / rstd2, gelu_d T [B N, F] (gelu'; NULL = not written: no backward will follow), a T [B N, F]; x2 X out */
+  const void* x; void* xn; float* mean1; float* rstd1; void* qkv; void* ctx; float* lse; void* x1; void* xn2; float* mean2; float* rstd2;
+  void* gelu_d; void* a; void* x2;
+  /* backward: g2 X (gradient of x2), g2t its T copy (== g2 when X is T), g2cs fp32 [E] column sums of g2 or NULL (computed here);
+   * workspaces dz T [B N, F], dxn2 T, g1 X, g1t T (== g1 when X is T or in fp32 mode), dctx T, dqkv T [B N, 3E], delta fp32 [B,H,N],
+   * dxn T; outputs g0 X (gradient of x), g0t T copy (== g0 when X is T or fp32 mode), g0cs fp32 [E] += column sums of g0 */
+  const void* g2; const void* g2t; const float* g2cs;
+  void* dz; void* dxn2; void* g1; void* g1t; void* dctx; void* dqkv; float* delta; void* dxn; void* g0; void* g0t; float* g0cs;
+  /* parameter gradients (fp32, accumulated) */
+  float *d_ln1_g, *d_ln1_b, *d_ln2_g, *d_ln2_b, *d_wqkv, *d_bqkv, *d_wo, *d_bo, *d_w1, *d_b1, *d_w2, *d_b2;
+} s4f_layer_desc;
+
+int s4f_encoder_layer_fwd(const s4f_layer_desc* d, s4f_stream stream);
+/* side_stream (or NULL: everything on `stream`): the weight-gradient group and the bias column sums run there behind
+ * fork_event (a hipEvent_t the caller created), which is recorded on `stream` at the points where their operands are final.
+ * The caller joins side_stream before it reads the parameter gradients. */
+int s4f_encoder_layer_bwd(const s4f_layer_desc* d, s4f_stream stream, s4f_stream side_stream, void* fork_event);
+
 /* ------------------------------------------------------------------------------------------- PUP head
  * BatchNorm batch statistics of x T [rows, C] (NHWC rows = B*H*W): sums[0:C] += sum, sums[C:2C] += sum of squares */
 int s4f_bn_stats(const void* x, int64_t rows, int C, float* sums, int dtype, s4f_stream stream);

@@ -44,7 +44,24 @@ class GemmDesc(Structure):
 assert ctypes.sizeof(GemmDesc) == 216, 'GemmDesc must mirror s4f_gemm_desc (include/s4f.h, static_assert in gemm.hip)'
 
 
+class LayerDesc(Structure):
+    """mirror of s4f_layer_desc (include/s4f.h)"""
+    _fields_ = ([(n, c_int32) for n in ('B', 'N', 'E', 'F', 'H', 'dtype', 'xdtype')] + [('eps', c_float), ('bias_w', c_float)] +
+                [('hint', c_int32 * 8), ('wg_hint', c_int32), ('wg_splitk', c_int32), ('fold_colsum', c_int32), ('reserved0', c_int32)] +
+                [(n, c_void_p) for n in (
+                    'ln1_g', 'ln1_b', 'ln2_g', 'ln2_b', 'bqkv', 'bo', 'b1', 'b2', 'wqkv', 'wo', 'w1', 'w2', 'wqkv_T', 'wo_T', 'w1_T', 'w2_T',
+                    'bias_u', 'row_flag',
+                    'x', 'xn', 'mean1', 'rstd1', 'qkv', 'ctx', 'lse', 'x1', 'xn2', 'mean2', 'rstd2', 'gelu_d', 'a', 'x2',
+                    'g2', 'g2t', 'g2cs', 'dz', 'dxn2', 'g1', 'g1t', 'dctx', 'dqkv', 'delta', 'dxn', 'g0', 'g0t', 'g0cs',
+                    'd_ln1_g', 'd_ln1_b', 'd_ln2_g', 'd_ln2_b', 'd_wqkv', 'd_bqkv', 'd_wo', 'd_bo', 'd_w1', 'd_b1', 'd_w2', 'd_b2')])
+
+
+assert ctypes.sizeof(LayerDesc) == 552, 'LayerDesc must mirror s4f_layer_desc (include/s4f.h, static_assert in layer.hip)'
+
+
 _SIGS = {
+    's4f_encoder_layer_fwd': [POINTER(LayerDesc), c_void_p],
+    's4f_encoder_layer_bwd': [POINTER(LayerDesc), c_void_p, c_void_p, c_void_p],
     's4f_gemm': [POINTER(GemmDesc), c_void_p],
     's4f_gemm_grouped': [POINTER(GemmDesc), c_int, c_void_p],
     's4f_cast': [c_void_p, c_void_p, c_int64, c_int, c_void_p],

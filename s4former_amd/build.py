@@ -13,7 +13,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 OBJ_DIR = os.path.join(CSRC, '_obj')
 LIB_PATH = os.path.join(PKG_DIR, 'libs4f_hip.so')
-SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm5.hip', 'gemm6.hip', 'attention.hip', 'elementwise.hip', 'head.hip', 'eval.hip', 'pipeline.hip']
+SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm5.hip', 'gemm6.hip', 'attention.hip', 'elementwise.hip', 'head.hip', 'eval.hip', 'pipeline.hip', 'layer.hip']
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 's4f.h')]
 BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off',
               '-Wno-unused-result', '-Wno-unused-value']

@@ -18,6 +18,7 @@ from torch.autograd import Function
 
 from . import kernels as K
 from . import runtime
+from . import _lib as L
 from ._lib import BF16, F32, S4FError
 
 SKIP_MASKED_COPY = os.environ.get('S4F_SKIP_MASKED_COPY', '1') != '0'     # A/B switch of head_backward's s = 1 stages
@@ -203,6 +204,11 @@ def _T(code):
     return torch.bfloat16 if code == BF16 else torch.float32
 
 
+def _lp(t):
+    """device pointer for a launch descriptor (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
 def _R(code):
     """torch dtype of the residual stream (token tensors between the layers and their gradients): fp32 in parity mode, the
     operand type in bf16 mode unless S4F_RESID=fp32 (runtime.residual_dtype)"""
@@ -341,6 +347,83 @@ class PatchEmbedFn(Function):
         return None, None, None, None, None, None
 
 
+
+# ============================================================================================== fused layer launches (round 3)
+# One C-ABI call per encoder-layer forward / backward (csrc/layer.hip) instead of one per kernel.  The per-kernel path below
+# stays: it is what runs under the profiler (bench.py's per-GEMM roofline accounting needs one event pair per GEMM), with
+# S4F_FUSED_LAUNCH=0, and for GEMM signatures the shipped tuning table does not know yet (they are tuned there on first use).
+FUSED_LAUNCH = os.environ.get('S4F_FUSED_LAUNCH', '1') != '0'
+_LAYER_PLANS = {}
+
+
+def _layer_plan(store, prm, M, E, F_, H, code, R):
+    """static part of a layer's launch descriptor: parameter / shadow / gradient pointers and the tuned tile variants of its
+    GEMMs; None when a signature is not in the tuning table yet (the per-kernel path then tunes it)"""
+    import ctypes
+    from . import _lib as L_
+    (g1, b1, wqkv, bqkv, wo, bo, g2, b2, w1, bf1, w2, bf2) = prm
+    key = (id(store), id(g1), M, code, R, store.flat.data_ptr(), 0 if store.flat_t is None else store.flat_t.data_ptr(),
+           0 if store.grad is None else store.grad.data_ptr())
+    plan = _LAYER_PLANS.get(key)
+    if plan is not None:
+        return plan
+    rt = R == torch.bfloat16
+    hints = [0] * 8
+    wg = (0, max(1, round(256 / (K._t256(F_, E) * 2 + K._t256(3 * E, E) + K._t256(E, E)))))
+    if code == BF16 and K.AUTOTUNE:
+        def sig(N_, K_, act, f32o, to, resid):
+            k = (K.OP_ROW, K.OP_ROW, M, N_, K_, K_, K_, None, act, False, f32o, to, resid, 1)
+            return k + ('resid_t',) if (resid and rt) else k
+        sigs = [sig(3 * E, E, K.ACT_NONE, False, True, False), sig(E, E, K.ACT_NONE, not rt, rt, True),
+                sig(F_, E, K.ACT_GELU, False, True, False), sig(E, F_, K.ACT_NONE, not rt, rt, True),
+                sig(F_, E, K.ACT_GELU_BWD, False, True, False), sig(E, F_, K.ACT_NONE, False, True, False),
+                sig(E, E, K.ACT_NONE, False, True, False), sig(E, 3 * E, K.ACT_NONE, False, True, False)]
+        for i, sg in enumerate(sigs):
+            ch = K._tuned_lookup(sg)
+            if ch is None:
+                return None
+            hints[i] = int(ch[0])
+        ch = K._tuned_lookup(('wgrad_grouped', (F_, E, M), (E, F_, M), (3 * E, E, M), (E, E, M)))
+        if ch is None:
+            return None
+        wg = (int(ch[0]), int(ch[1]))
+    elif code == BF16:
+        wg = (4, wg[1])
+    d = L_.LayerDesc()
+    d.E, d.F, d.H, d.dtype, d.xdtype = E, F_, H, code, (BF16 if rt else F32)
+    for i in range(8):
+        d.hint[i] = hints[i]
+    d.wg_hint, d.wg_splitk, d.fold_colsum = wg[0], wg[1], 1 if K.FOLD_COLSUM else 0
+    ph, gr, sh = store.phys, store.grad_phys, store.shadow
+    for name, t in (('ln1_g', g1), ('ln1_b', b1), ('ln2_g', g2), ('ln2_b', b2), ('bqkv', bqkv), ('bo', bo), ('b1', bf1), ('b2', bf2)):
+        setattr(d, name, ph(t).data_ptr())
+    for name, t in (('wqkv', wqkv), ('wo', wo), ('w1', w1), ('w2', w2)):
+        setattr(d, name, sh(t).data_ptr())
+    if store.grad is not None:
+        for name, t in (('d_ln1_g', g1), ('d_ln1_b', b1), ('d_ln2_g', g2), ('d_ln2_b', b2), ('d_wqkv', wqkv), ('d_bqkv', bqkv), ('d_wo', wo),
+                        ('d_bo', bo), ('d_w1', w1), ('d_b1', bf1), ('d_w2', w2), ('d_b2', bf2)):
+            setattr(d, name, gr(t).data_ptr())
+    plan = dict(desc=d, T_set=False, event=None)
+    _LAYER_PLANS[key] = plan
+    return plan
+
+
+def _plan_backward_ready(plan, store, prm, code, dev):
+    """transposed weight shadows (bf16) registered / fresh, the fork event created"""
+    (_, _, wqkv, _, wo, _, _, _, w1, _, w2, _) = prm
+    d = plan['desc']
+    if code == BF16:
+        if not plan['T_set'] or not store._T_fresh or store._T_event is not None:
+            for name, t in (('wqkv_T', wqkv), ('wo_T', wo), ('w1_T', w1), ('w2_T', w2)):
+                setattr(d, name, store.shadow_T(t).data_ptr())          # (registers on first use, re-syncs / waits when stale)
+            plan['T_set'] = True
+    if plan['event'] is None:
+        ev = torch.cuda.Event()
+        ev.record()                                                      # instantiates the underlying hipEvent_t
+        plan['event'] = ev
+    return plan['event']
+
+
 # ============================================================================================== encoder layer
 class LayerFn(Function):
     """x [B,N,E] fp32 -> x + MHA(LN1(x)) -> (+ FFN(LN2(.)))   (vit.py:113-127)"""
@@ -355,28 +438,37 @@ class LayerFn(Function):
         F_ = w1.shape[0]
         dev = x.device
         x = x.contiguous()
+        R = x.dtype
+        need_grad = any(ctx.needs_input_grad)
         xn = torch.empty(M, E, device=dev, dtype=T)
         mean1 = torch.empty(M, device=dev); rstd1 = torch.empty(M, device=dev)
-        K.layernorm_fwd(x, store.phys(g1), store.phys(b1), xn, mean1, rstd1, M, E, code, eps)
         qkv = torch.empty(M, 3 * E, device=dev, dtype=T)
-        K.gemm(xn, store.shadow(wqkv), M, 3 * E, E, E, E, code, bias=store.phys(bqkv), out_t=qkv, ldo_t=3 * E)
         ctxv = torch.empty(M, E, device=dev, dtype=T)
         lse = torch.empty(Bn, num_heads, N, device=dev)
-        K.attention_fwd(qkv, ctxv, lse, Bn, N, num_heads, code, bias_u=bias_u, row_flag=row_flag, bias_w=bias_w)
-        R = x.dtype
         x1 = torch.empty(Bn, N, E, device=dev, dtype=R)
-        _gemm_resid(ctxv, store.shadow(wo), M, E, E, code, store.phys(bo), x, x1)
         xn2 = torch.empty(M, E, device=dev, dtype=T)
         mean2 = torch.empty(M, device=dev); rstd2 = torch.empty(M, device=dev)
-        K.layernorm_fwd(x1, store.phys(g2), store.phys(b2), xn2, mean2, rstd2, M, E, code, eps)
-        need_grad = any(ctx.needs_input_grad)
         # gelu'(z) is written only when a backward pass will read it (never on the teacher / inference path)
         z = torch.empty(M, F_, device=dev, dtype=T) if need_grad else None
         a = torch.empty(M, F_, device=dev, dtype=T)
-        K.gemm(xn2, store.shadow(w1), M, F_, E, E, E, code, bias=store.phys(bf1), out_t=a, ldo_t=F_, out_pre=z, ldo_pre=F_ if need_grad else 0,
-               act=K.ACT_GELU)
         x2 = torch.empty(Bn, N, E, device=dev, dtype=R)
-        _gemm_resid(a, store.shadow(w2), M, E, F_, code, store.phys(bf2), x1, x2)
+        plan = _layer_plan(store, prm, M, E, F_, num_heads, code, R) if (FUSED_LAUNCH and L._prof is None) else None
+        if plan is not None:
+            d = plan['desc']
+            d.B, d.N, d.eps, d.bias_w = Bn, N, eps, float(bias_w)
+            d.bias_u, d.row_flag = _lp(bias_u), _lp(row_flag)
+            d.x, d.xn, d.mean1, d.rstd1, d.qkv, d.ctx, d.lse = x.data_ptr(), xn.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), qkv.data_ptr(), ctxv.data_ptr(), lse.data_ptr()
+            d.x1, d.xn2, d.mean2, d.rstd2, d.gelu_d, d.a, d.x2 = x1.data_ptr(), xn2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), _lp(z), a.data_ptr(), x2.data_ptr()
+            L.call('s4f_encoder_layer_fwd', d, L.stream())
+        else:
+            K.layernorm_fwd(x, store.phys(g1), store.phys(b1), xn, mean1, rstd1, M, E, code, eps)
+            K.gemm(xn, store.shadow(wqkv), M, 3 * E, E, E, E, code, bias=store.phys(bqkv), out_t=qkv, ldo_t=3 * E)
+            K.attention_fwd(qkv, ctxv, lse, Bn, N, num_heads, code, bias_u=bias_u, row_flag=row_flag, bias_w=bias_w)
+            _gemm_resid(ctxv, store.shadow(wo), M, E, E, code, store.phys(bo), x, x1)
+            K.layernorm_fwd(x1, store.phys(g2), store.phys(b2), xn2, mean2, rstd2, M, E, code, eps)
+            K.gemm(xn2, store.shadow(w1), M, F_, E, E, E, code, bias=store.phys(bf1), out_t=a, ldo_t=F_, out_pre=z, ldo_pre=F_ if need_grad else 0,
+                   act=K.ACT_GELU)
+            _gemm_resid(a, store.shadow(w2), M, E, F_, code, store.phys(bf2), x1, x2)
         if need_grad:
             ctx.store, ctx.prm = store, prm
             ctx.range = store.range_of(prm)
@@ -400,53 +492,70 @@ class LayerFn(Function):
         R = g2.dtype                              # residual-stream type: the gradient stream has it too
         g2t = g2 if R == T else _as_T(g2, code)
         g2cs = _handed_colsum(g2)
-        # ---- FFN
-        # The four weight gradients of the layer go out as ONE grouped launch on the side stream once the last operand
-        # (dqkv) exists: alone each has 9..36 output tiles and needs a deep split-K; together they fill the chip.
         a_act, xn2, ctxv, xn = sv['a'], sv['xn2'], sv['ctxv'], sv['xn']
-        if g2cs is None:
-            with on_side(dev, g2t):
-                K.colsum(g2t, E, M, E, store.grad_phys(bf2), code)
-        else:
-            store.grad_phys(bf2).add_(g2cs)
         dz = torch.empty(M, F_, device=dev, dtype=T)
-        # (the fc1 bias gradient = column sums of dz comes out of the GEMM's staged output tile where the variant allows)
-        folded = _dgrad(g2t, w2, M, F_, E, store, code, out_t=dz, ldo_t=F_, aux=sv['z'], ld_aux=F_, act=K.ACT_GELU_BWD,
-                        colsum=store.grad_phys(bf1))
-        sv['z'] = sv['a'] = None
-        if not folded:
-            with on_side(dev, dz):
-                K.colsum(dz, F_, M, F_, store.grad_phys(bf1), code)
         dxn2 = torch.empty(M, E, device=dev, dtype=T)
-        _dgrad(dz, w1, M, E, F_, store, code, out_t=dxn2, ldo_t=E)
         g1 = torch.empty(Bn, N, E, device=dev, dtype=R)
-        g1t = torch.empty(Bn, N, E, device=dev, dtype=T) if (code == BF16 and R != T) else None
-        # the column sums of g1 (= the proj bias gradient) come out of the same pass
-        K.layernorm_bwd(dxn2, sv['x1'], sv['mean2'], sv['rstd2'], store.phys(gm2), g2, g1, g1t, store.grad_phys(gm2),
-                        store.grad_phys(b2), M, E, code, dcolsum=store.grad_phys(bo))
-        if g1t is None:
-            g1t = g1
-        # ---- attention
+        g1t = torch.empty(Bn, N, E, device=dev, dtype=T) if (code == BF16 and R != T) else g1
         dctx = torch.empty(M, E, device=dev, dtype=T)
-        _dgrad(g1t, wo, M, E, E, store, code, out_t=dctx, ldo_t=E)
         dqkv = torch.empty(M, 3 * E, device=dev, dtype=T)
         delta = torch.empty(Bn, H, N, device=dev)
-        K.attention_bwd(sv['qkv'], sv['ctxv'], dctx, sv['lse'], delta, dqkv, Bn, N, H, code, bias_u=sv['bias_u'],
-                        row_flag=sv['row_flag'], bias_w=bias_w)
-        with on_side(dev, dqkv, xn, dz, xn2, g1t, ctxv, g2t, a_act, enable=LAYER_WG_SIDE):
-            K.wgrad_grouped([(dz, xn2, F_, E, M, store.grad_phys(w1)),
-                             (g2t, a_act, E, F_, M, store.grad_phys(w2)),
-                             (dqkv, xn, 3 * E, E, M, store.grad_phys(wqkv)),
-                             (g1t, ctxv, E, E, M, store.grad_phys(wo))], code)
-            K.colsum(dqkv, 3 * E, M, 3 * E, store.grad_phys(bqkv), code)
         dxn = torch.empty(M, E, device=dev, dtype=T)
-        _dgrad(dqkv, wqkv, M, E, 3 * E, store, code, out_t=dxn, ldo_t=E)
-        del dqkv, dz
         g0 = torch.empty(Bn, N, E, device=dev, dtype=R)
         g0t = torch.empty(Bn, N, E, device=dev, dtype=T) if (code == BF16 and R != T) else None
         g0cs = zeros_small(E, dev)
-        K.layernorm_bwd(dxn, sv['x'], sv['mean1'], sv['rstd1'], store.phys(gm1), g1, g0, g0t, store.grad_phys(gm1),
-                        store.grad_phys(b1), M, E, code, dcolsum=g0cs)
+        plan = _layer_plan(store, ctx.prm, M, E, F_, H, code, R) if (FUSED_LAUNCH and L._prof is None) else None
+        if plan is not None:
+            ev = _plan_backward_ready(plan, store, ctx.prm, code, dev)
+            d = plan['desc']
+            d.B, d.N, d.bias_w = Bn, N, float(bias_w)
+            d.bias_u, d.row_flag = _lp(sv['bias_u']), _lp(sv['row_flag'])
+            d.x, d.xn, d.mean1, d.rstd1, d.qkv, d.ctx, d.lse = sv['x'].data_ptr(), xn.data_ptr(), sv['mean1'].data_ptr(), sv['rstd1'].data_ptr(), sv['qkv'].data_ptr(), ctxv.data_ptr(), sv['lse'].data_ptr()
+            d.x1, d.xn2, d.mean2, d.rstd2, d.gelu_d, d.a = sv['x1'].data_ptr(), xn2.data_ptr(), sv['mean2'].data_ptr(), sv['rstd2'].data_ptr(), sv['z'].data_ptr(), a_act.data_ptr()
+            d.g2, d.g2t, d.g2cs = g2.data_ptr(), g2t.data_ptr(), _lp(g2cs)
+            d.dz, d.dxn2, d.g1, d.g1t, d.dctx, d.dqkv, d.delta, d.dxn = dz.data_ptr(), dxn2.data_ptr(), g1.data_ptr(), g1t.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), delta.data_ptr(), dxn.data_ptr()
+            d.g0, d.g0t, d.g0cs = g0.data_ptr(), (g0t if g0t is not None else g0).data_ptr(), g0cs.data_ptr()
+            use_side = USE_SIDE_STREAM and LAYER_WG_SIDE
+            side = side_stream(dev) if use_side else None
+            L.call('s4f_encoder_layer_bwd', d, L.stream(), side.cuda_stream if side is not None else None, ev.cuda_event if side is not None else None)
+            if side is not None:
+                for t in (dqkv, xn, dz, xn2, g1t, ctxv, g2t, a_act):
+                    t.record_stream(side)           # allocated on the chain's stream, read by the weight-gradient stream
+            sv['z'] = sv['a'] = None
+        else:
+            # ---- FFN
+            # The four weight gradients of the layer go out as ONE grouped launch on the side stream once the last operand
+            # (dqkv) exists: alone each has 9..36 output tiles and needs a deep split-K; together they fill the chip.
+            if g2cs is None:
+                with on_side(dev, g2t):
+                    K.colsum(g2t, E, M, E, store.grad_phys(bf2), code)
+            else:
+                store.grad_phys(bf2).add_(g2cs)
+            # (the fc1 bias gradient = column sums of dz comes out of the GEMM's staged output tile where the variant allows)
+            folded = _dgrad(g2t, w2, M, F_, E, store, code, out_t=dz, ldo_t=F_, aux=sv['z'], ld_aux=F_, act=K.ACT_GELU_BWD,
+                            colsum=store.grad_phys(bf1))
+            sv['z'] = sv['a'] = None
+            if not folded:
+                with on_side(dev, dz):
+                    K.colsum(dz, F_, M, F_, store.grad_phys(bf1), code)
+            _dgrad(dz, w1, M, E, F_, store, code, out_t=dxn2, ldo_t=E)
+            # the column sums of g1 (= the proj bias gradient) come out of the same pass
+            K.layernorm_bwd(dxn2, sv['x1'], sv['mean2'], sv['rstd2'], store.phys(gm2), g2, g1, g1t if g1t is not g1 else None, store.grad_phys(gm2),
+                            store.grad_phys(b2), M, E, code, dcolsum=store.grad_phys(bo))
+            # ---- attention
+            _dgrad(g1t, wo, M, E, E, store, code, out_t=dctx, ldo_t=E)
+            K.attention_bwd(sv['qkv'], sv['ctxv'], dctx, sv['lse'], delta, dqkv, Bn, N, H, code, bias_u=sv['bias_u'],
+                            row_flag=sv['row_flag'], bias_w=bias_w)
+            with on_side(dev, dqkv, xn, dz, xn2, g1t, ctxv, g2t, a_act, enable=LAYER_WG_SIDE):
+                K.wgrad_grouped([(dz, xn2, F_, E, M, store.grad_phys(w1)),
+                                 (g2t, a_act, E, F_, M, store.grad_phys(w2)),
+                                 (dqkv, xn, 3 * E, E, M, store.grad_phys(wqkv)),
+                                 (g1t, ctxv, E, E, M, store.grad_phys(wo))], code)
+                K.colsum(dqkv, 3 * E, M, 3 * E, store.grad_phys(bqkv), code)
+            _dgrad(dqkv, wqkv, M, E, 3 * E, store, code, out_t=dxn, ldo_t=E)
+            K.layernorm_bwd(dxn, sv['x'], sv['mean1'], sv['rstd1'], store.phys(gm1), g1, g0, g0t, store.grad_phys(gm1),
+                            store.grad_phys(b1), M, E, code, dcolsum=g0cs)
+        del dqkv, dz
         # reused by the previous layer if autograd hands this very tensor through unmodified (autograd may
         # accumulate other branches into it in place: the version counter catches that)
         if g0t is not None:
