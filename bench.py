@@ -166,6 +166,7 @@ def main():
     model.to(dev)
     model.log_vars_as_tensors = True              # no host sync inside the step
     opt = S.build_optimizer(model, dict(OPTIMIZER))
+    opt.fused_zero_grad = os.environ.get('S4F_FUSED_ZERO_GRAD', '1') != '0'     # the SGD kernels zero the gradients they consume
     sched = S.PolyLR(opt, MAX_ITERS)
 
     batches = [synthetic_batch(1999 + 17 * rank + i, n_sup, n_unsup, img=img, num_classes=ncls, device=dev, **bkw) for i in range(2)]

@@ -351,8 +351,9 @@ int s4f_ema(float* teacher, const float* student, void* teacher_t, int64_t n, fl
             float one_minus_momentum, int dtype, s4f_stream stream);
 /* torch.optim.SGD(momentum, wd=0, dampening 0, nesterov False): first_step: buf = g else buf = mom*buf + g;
  * p -= lr*buf; optional T shadow of p; grad_scale multiplies g first (DDP mean). Segments with different lr
- * are separate calls on sub-ranges of the arenas. */
-int s4f_sgd_momentum(float* p, const float* g, float* buf, void* p_t, int64_t n, float lr, float momentum,
+ * are separate calls on sub-ranges of the arenas.  first_step: bit 0 = first step, bit 1 (round 3) = write zeros over the
+ * gradient range after it has been consumed (optimizer.zero_grad() of the next step folded into this pass). */
+int s4f_sgd_momentum(float* p, float* g, float* buf, void* p_t, int64_t n, float lr, float momentum,
                      float grad_scale, int first_step, int dtype, s4f_stream stream);
 
 #ifdef __cplusplus

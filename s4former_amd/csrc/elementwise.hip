@@ -347,8 +347,10 @@ __global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, T
 }
 
 template <typename T>
-__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                           T* __restrict__ pt, long n, float lr, float mom, float gs, int first) {
+__global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
+                           T* __restrict__ pt, long n, float lr, float mom, float gs, int flags) {
+  const int first = flags & 1;
+  const bool zero = (flags & 2) != 0;          // leave the gradient range zeroed (the next step's zero_grad() has nothing to do)
   const long n4 = n >> 2;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
@@ -364,6 +366,7 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     reinterpret_cast<f32x4*>(buf)[i] = bv;
     reinterpret_cast<f32x4*>(p)[i] = pv;
     if (pt) store4<T>(pt + 4 * i, pv);
+    if (zero) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const float ge = gs == 1.f ? g[i] : __fmul_rn(g[i], gs);
@@ -371,6 +374,7 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     const float v = __fmaf_rn(b, -lr, p[i]);
     buf[i] = b; p[i] = v;
     if (pt) pt[i] = from_f32<T>(v);
+    if (zero) g[i] = 0.f;
   }
 }
 
@@ -656,7 +660,7 @@ S4F_API int s4f_ema(float* teacher, const float* student, void* teacher_t, int64
   return 0;
 }
 
-S4F_API int s4f_sgd_momentum(float* p, const float* g, float* buf, void* p_t, int64_t n, float lr, float momentum,
+S4F_API int s4f_sgd_momentum(float* p, float* g, float* buf, void* p_t, int64_t n, float lr, float momentum,
                              float grad_scale, int first_step, int dtype, s4f_stream stream) {
   DT_CHECK("s4f_sgd_momentum");
   S4F_CHECK(p && g && buf && n > 0, "s4f_sgd_momentum: bad args");

@@ -699,9 +699,10 @@ def ema(teacher, student, teacher_t, n, momentum, dtype):
          float(np.float32(1 - momentum)), dtype, stream())
 
 
-def sgd_momentum(param, grad, buf, param_t, n, lr, momentum, grad_scale, first_step, dtype):
+def sgd_momentum(param, grad, buf, param_t, n, lr, momentum, grad_scale, first_step, dtype, zero_grad=False):
+    """zero_grad=True: the gradient range is left zeroed (the next optimizer.zero_grad() then has nothing to do)"""
     for t in (param, grad, buf):
         _chk_f32(t, 'sgd'); _need(t, n, 'sgd')
     _chk_dtype(param_t, dtype, 'sgd param_t'); _need(param_t, n if param_t is not None else 0, 'sgd param_t')
     call('s4f_sgd_momentum', p(param), p(grad), p(buf), p(param_t), n, float(np.float32(lr)), float(np.float32(momentum)),
-         float(np.float32(grad_scale)), 1 if first_step else 0, dtype, stream())
+         float(np.float32(grad_scale)), (1 if first_step else 0) | (2 if zero_grad else 0), dtype, stream())

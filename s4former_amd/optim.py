@@ -37,6 +37,10 @@ class S4FSGD(torch.optim.Optimizer):
         self._eager = None           # (store, reducer, grad_scale) when ranges are stepped during backward
         self._eager_done = []        # [(a, b)] arena ranges already stepped in this iteration
         self._stream = None
+        # Extension (off by default: torch leaves .grad untouched by step()): the SGD kernels write zeros over the gradient
+        # ranges they consume, and the zero_grad() of the next iteration - a 400 MB fill alone on the GPU at the start of the
+        # step - has nothing left to do (ParamStore.grad_clean).  bench.py switches it on.
+        self.fused_zero_grad = os.environ.get('S4F_FUSED_ZERO_GRAD', '0') == '1'
 
     def _plan(self):
         """[(group_name, a, b, [param_group indices])] over the student arena"""
@@ -112,7 +116,8 @@ class S4FSGD(torch.optim.Optimizer):
                 handle.wait()
             pt = store.flat_t[a:b] if store.flat_t is not None else None
             K.sgd_momentum(store.flat[a:b], store.grad[a:b], store.mom[a:b], pt, b - a, lm[0], lm[1], scale,
-                           store.first_sgd_step, store.dtype)
+                           store.first_sgd_step, store.dtype, zero_grad=self.fused_zero_grad)
+            store.sync_T_range(a, b)                 # the transposed operand shadows of this range, behind its update
         self._eager_done.append((a, b, stream))
 
     @torch.no_grad()
@@ -135,7 +140,7 @@ class S4FSGD(torch.optim.Optimizer):
                     if da > pos:
                         pt = store.flat_t[pos:da] if store.flat_t is not None else None
                         K.sgd_momentum(store.flat[pos:da], store.grad[pos:da], store.mom[pos:da], pt, da - pos, lm[0], lm[1],
-                                       grad_scale, first, store.dtype)
+                                       grad_scale, first, store.dtype, zero_grad=self.fused_zero_grad)
                     pos = max(pos, db)
             else:
                 for e in store.entries:
@@ -145,8 +150,9 @@ class S4FSGD(torch.optim.Optimizer):
                     n = (e.numel + 63) // 64 * 64
                     pt = store.flat_t[e.off:e.off + n] if store.flat_t is not None else None
                     K.sgd_momentum(store.flat[e.off:e.off + n], store.grad[e.off:e.off + n], store.mom[e.off:e.off + n], pt,
-                                   n, g['lr'], g['momentum'], grad_scale, first, store.dtype)
+                                   n, g['lr'], g['momentum'], grad_scale, first, store.dtype, zero_grad=self.fused_zero_grad)
         store.first_sgd_step = False
+        store.grad_clean = bool(self.fused_zero_grad)      # every parameter range has been consumed and zeroed
         if store.flat_t is not None and store._T_items:
             store.sync_T(eager=True)      # transposed operand shadows follow the bf16 shadow the SGD kernels just wrote
         return loss

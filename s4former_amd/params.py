@@ -200,16 +200,52 @@ class ParamStore:
         dev = torch.tensor([v for it in items for v in it], dtype=torch.int64, device=self.flat.device)
         self._T_table = (dev, items)
 
+    def _T_subtable(self, offs):
+        """item table (device int64, host list) of the registered transposes at the given arena offsets; cached"""
+        key = tuple(offs)
+        cache = self.__dict__.setdefault('_T_sub', {})
+        if key not in cache:
+            items, total = [], 0
+            for off in offs:
+                R, T, C = self._T_items[off]
+                items.append((off, off, R, T, C, total))
+                total += T * (R // 64) * (C // 64)
+            dev = torch.tensor([v for it in items for v in it], dtype=torch.int64, device=self.flat.device)
+            cache[key] = (dev, items)
+        return cache[key]
+
+    def sync_T_range(self, a, b):
+        """the transposed shadows of the weights inside arena range [a, b), on the current stream (the eager optimiser calls this
+        right behind the SGD launch of the range: the one whole-arena transpose launch at the end of step() then only covers what
+        was not stepped eagerly)"""
+        if self.flat_t is None or not self._T_items or self.flat_T is None:
+            return
+        offs = [off for off in sorted(self._T_items) if a <= off < b]
+        if not offs:
+            return
+        dev, items = self._T_subtable(offs)
+        K.transpose_many(self.flat_t, self.flat_T, dev, items)
+        self.__dict__.setdefault('_T_done', set()).update(offs)
+
     def sync_T(self, eager=False):
         """(re)make every registered transposed shadow from the bf16 shadow arena in ONE launch on the current stream.
-        eager=True: called on the optimiser's stream right after the SGD kernels; every stream of the next step forks
-        from that stream, so no event is needed.  Otherwise users wait for the recorded event."""
+        eager=True: called on the optimiser's stream right after the SGD kernels (ranges already transposed behind their eager
+        update - sync_T_range - are left out); every stream of the next step forks from that stream, so no event is needed.
+        Otherwise users wait for the recorded event."""
         if not self._T_items:
             self._T_fresh = True
             return
-        if self._T_table is None:
-            self._T_rebuild_table()
-        K.transpose_many(self.flat_t, self.flat_T, self._T_table[0], self._T_table[1])
+        done = self.__dict__.pop('_T_done', set()) if eager else set()
+        self.__dict__.pop('_T_done', None)
+        if done:
+            rest = [off for off in sorted(self._T_items) if off not in done]
+            if rest:
+                dev, items = self._T_subtable(rest)
+                K.transpose_many(self.flat_t, self.flat_T, dev, items)
+        else:
+            if self._T_table is None:
+                self._T_rebuild_table()
+            K.transpose_many(self.flat_t, self.flat_T, self._T_table[0], self._T_table[1])
         self._T_fresh = True
         if eager:
             self._T_event = None
@@ -237,6 +273,7 @@ class ParamStore:
                 self.flat_T = torch.zeros(self.total, device=self.flat.device, dtype=torch.bfloat16)
             self._T_items[e.off] = dims
             self._T_table = None
+            self.__dict__.pop('_T_sub', None)
             self._T_fresh = False
             e.v_T = self.flat_T[e.off:e.off + e.numel]
         if not self._T_fresh:
@@ -316,6 +353,7 @@ class ParamStore:
     # accumulation) is therefore reported once, after the second backward.  A graph that is never run backward leaves its
     # count above zero: the range is then simply not reported early and falls to reduce_() / step(), which cover the rest.
     def range_acquire(self, rng):
+        self.grad_clean = False                      # a backward pass will accumulate into the gradient arena
         ep = getattr(self, 'step_epoch', 0)
         if getattr(self, '_pend_epoch', None) != ep:
             self._pend, self._pend_epoch = {}, ep
@@ -331,7 +369,7 @@ class ParamStore:
             self.range_done(*rng)
 
     def zero_grad(self):
-        if self.grad is not None:
+        if self.grad is not None and not getattr(self, 'grad_clean', False):
             self.grad.zero_()
 
     def named_entries(self):

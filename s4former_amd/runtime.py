@@ -30,7 +30,7 @@ def compute_dtype_name():
 # Residual stream (token tensors between the encoder layers and their gradients, vit.py:113-127): fp32 in both modes by
 # default.  S4F_RESID=bf16 keeps it in bf16 in bf16 mode (kernels and tests exist: round 3).  Measured on the default workload
 # (profiles/r03_*): the step gains 0.24 ms (30.76 -> 30.51 ms: the LayerNorm passes are latency-bound, not HBM-bound) while the
-# gradient arena's cosine against the fp32 step falls from 0.99995 to 0.9987 (relative error ~1 % -> ~5 %) - not worth it.
+# gradient arena's cosine against the fp32 step falls from 0.99939 to 0.99872 at cfg2 (relative error 3.5 % -> 5.1 %) - not worth it.
 _resid_fp32 = os.environ.get('S4F_RESID', 'fp32').lower() not in ('bf16', 'bfloat16')
 
 

@@ -139,7 +139,7 @@ def test_step_vs_golden(name, dtype):
 
 def test_step_with_the_bf16_residual_stream(monkeypatch):
     """opt-in S4F_RESID=bf16 (runtime.set_residual_fp32(False)): token tensors between the layers and their gradients in bf16.
-    Not the default - at DeiT-B size the gradient arena's cosine against the fp32 step falls from 0.99995 to 0.9987 for 0.24 ms
+    Not the default - at DeiT-B size the gradient arena's cosine against the fp32 step falls from 0.99939 to 0.99872 for 0.24 ms
     of the step - but the path (typed LayerNorm, bf16 residual GEMM epilogues, typed token assembly) stays held to the golden."""
     from s4former_amd import runtime
     z, meta = load_gold('mt_pasa')
@@ -157,6 +157,26 @@ def test_step_with_the_bf16_residual_stream(monkeypatch):
         assert abs(rec[0]['gn'][k] - v) <= 8e-2 * (abs(v) + 1e-12), (k, rec[0]['gn'][k], v)
     C.check_grad_samples(z, 0, _SampleView(rec[0]['g']), 3e-1, msgs, rec='tiny/mt_pasa/bf16/resid_bf16', mtol=0.12)
     assert not msgs, '\n'.join(msgs)
+
+
+def test_sgd_that_zeroes_the_gradients_it_consumes():
+    """optimizer.fused_zero_grad (bench.py's setting): the SGD kernels leave the gradient arena zeroed, zero_grad() of the next
+    iteration is then skipped - two steps end in the same state as with the separate fill, and the arena is clean after step()"""
+    z, meta = load_gold('mt_pasa')
+    finals = []
+    for fused in (False, True):
+        model, opt, sched = build_product(meta, 'fp32')
+        opt.fused_zero_grad = fused
+        run_product(model, opt, sched, meta, iters=2)
+        store = model.student_store
+        if fused:
+            assert getattr(store, 'grad_clean', False) and float(store.grad.abs().max()) == 0.0
+        else:
+            assert float(store.grad.abs().max()) > 0.0
+        finals.append({k: v.detach().double().clone() for k, v in model.state_dict().items() if v.dtype.is_floating_point})
+    for k in finals[0]:
+        a, b = finals[0][k], finals[1][k]
+        assert float((a - b).abs().max()) <= 1e-4 * (float(a.abs().max()) + 1e-12) + 1e-9, k      # (two runs: the split-K atomics differ in their last bits)
 
 
 LOGIT_TOL = 2e-5     # stated bound on the fp32-mode teacher logits' deviation, relative to max |logit|
