@@ -35,7 +35,6 @@ struct GemmArgs {
   int tail_rows;                                   // rows folded into the last tile row (0: none)
   int zgroup;                                      // split-K blocks of one k-range are placed on one XCD (0: off)
   int sk;                                          // number of k-ranges
-  int stagger_phases, stagger_units;               // first-round blocks of phase p start p * units * 1024 clocks late (0: off)
 };
 
 constexpr int BM = 256, BK = 64;

@@ -23,7 +23,6 @@
 // family (shared code of gemm2.hip).  A row remainder of <= 16 rows is folded into the last tile row like in gemm2.hip.
 #define G2_NS g5
 #define G2_VARIANT_ONLY 1
-#include <stdlib.h>
 #include "gemm2.hip"
 
 namespace g5 {
@@ -472,12 +471,6 @@ __global__ __launch_bounds__(512) void gemm5_kernel(const GemmArgs args) {
   // XCD-aware bijective remap + grouped tile order (as gemm2.hip)
   const int nt = args.tiles_m * args.tiles_n;
   int L = blockIdx.x;
-  if (args.stagger_phases > 1 && blockIdx.x < 256 && blockIdx.z == 0) {
-    // de-synchronise the chip: the CUs of phase p run p * units * ~0.5 us behind, so that the store bursts of the tiles'
-    // epilogues (HBM-bound when all 256 CUs reach them together) fall under the other phases' K loops
-    const int ph = (blockIdx.x >> 3) % args.stagger_phases;
-    for (int i = 0; i < ph * args.stagger_units; ++i) __builtin_amdgcn_s_sleep(16);
-  }
   {
     const int xcd = L & 7, q8 = nt >> 3, r8 = nt & 7;
     const int basei = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
@@ -505,11 +498,6 @@ int launch5(const s4f_gemm_desc& d, hipStream_t st) {
   a.tiles_n = ceil_div(d.N, 256);
   a.sk = sk;
   a.zgroup = 0;
-  a.stagger_phases = a.stagger_units = 0;
-  if (const char* e = getenv("S4F_G5_STAGGER")) {
-    int ph = 0, un = 0;
-    if (sscanf(e, "%d,%d", &ph, &un) == 2) a.stagger_phases = ph, a.stagger_units = un;
-  }
   const int rem = d.M % BM;
   if (AMODE == S4F_OP_ROW && rem > 0 && rem <= TAIL_MAX && d.M > BM) {
     a.tiles_m = d.M / BM;
@@ -529,7 +517,6 @@ int launch5(const s4f_gemm_desc& d, hipStream_t st) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
-  if (a.tiles_m * a.tiles_n * sk <= 256) a.stagger_phases = 0;      // one round: nothing to interleave with
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, 1, sk), dim3(512), shm, st, a);
   return 0;
 }
