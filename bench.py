@@ -169,6 +169,9 @@ def main():
     opt.fused_zero_grad = os.environ.get('S4F_FUSED_ZERO_GRAD', '1') != '0'     # the SGD kernels zero the gradients they consume
     sched = S.PolyLR(opt, MAX_ITERS)
 
+    if os.environ.get('S4F_PRETOUCH'):              # experiment: first-use order of the streams = who shares a hardware queue
+        from s4former_amd.functional import pretouch_streams
+        pretouch_streams(dev, [x for x in os.environ['S4F_PRETOUCH'].split(',') if x], opt)
     batches = [synthetic_batch(1999 + 17 * rank + i, n_sup, n_unsup, img=img, num_classes=ncls, device=dev, **bkw) for i in range(2)]
     reducer = setup_data_parallel(model, opt, dev)   # replicas made identical, per-range all-reduce + eager SGD hooked in
 
@@ -254,6 +257,10 @@ def main():
                             student_passes=2 if flags.get('attn_mask_seperate_head') else 1)
     step_tflops = gflop_step * args.steps / dt / 1e3          # per GPU
 
+    if os.environ.get('S4F_LAYOUT_REPORT'):
+        from s4former_amd.functional import check_stream_layout
+        print('[layout]', os.environ.get('S4F_PRETOUCH', '-'), f'{dt / args.steps * 1e3:.3f} ms/step',
+              check_stream_layout(dev, extra=[('opt', getattr(opt, '_stream', None))]), file=sys.stderr, flush=True)
     # ---- host cost of one step, measured from an IDLE device (nothing queued: no back-pressure from a full HIP queue in it);
     # host_enqueue_ms_per_step above is the average inside the timed region, where submits can block on the queue
     torch.cuda.synchronize()

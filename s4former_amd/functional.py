@@ -86,7 +86,30 @@ def lay_out_streams(device):
 _burn = []
 
 
-def check_stream_layout(device, cycles=400_000):
+def pretouch_streams(device, order, optimizer=None):
+    """use the package's streams for the first time in a given order ('decode', 'aux', 'side', 'opt', 'burn' = a throw-away
+    stream): the runtime binds a stream to one of its four hardware queues at its FIRST use, so the order decides which streams
+    share a queue (two streams on one queue serialise)."""
+    def touch(st):
+        with torch.cuda.stream(st):
+            torch.empty(64, device=device).fill_(0.0)
+    for name in order:
+        if name == 'burn':
+            _burn.append(torch.cuda.Stream(device=device))
+            touch(_burn[-1])
+        elif name == 'side':
+            touch(side_stream(device))
+        elif name == 'opt':
+            if optimizer is not None:
+                if getattr(optimizer, '_stream', None) is None:
+                    optimizer._stream = torch.cuda.Stream(device=device)
+                touch(optimizer._stream)
+        else:
+            touch(head_stream(device, name))
+    torch.cuda.synchronize(device)
+
+
+def check_stream_layout(device, cycles=400_000, extra=()):
     """Do the chain's stream, the two head streams and the weight-gradient stream run CONCURRENTLY (= sit on different hardware
     queues)?  Two single-thread spin kernels (torch.cuda._sleep) started together on a pair of streams take about one spin if
     the streams are on different queues and two if they share one.  Returns dict(ok=bool, pairs={name: ratio}); ok = every
@@ -94,7 +117,7 @@ def check_stream_layout(device, cycles=400_000):
     res = dict(ok=False, pairs={})
     try:
         names = [('main', torch.cuda.current_stream(device)), ('decode', head_stream(device, 'decode')), ('aux', head_stream(device, 'aux')),
-                 ('side', side_stream(device))]
+                 ('side', side_stream(device))] + [(n, st) for n, st in extra if st is not None]
 
         def timed(streams):
             torch.cuda.synchronize(device)
