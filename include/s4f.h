@@ -267,7 +267,8 @@ int s4f_upce_fwd(const float* logits_lo, const uint8_t* labels, float* loss_sum,
                  int C, int ldc, int s, int ignore_index, s4f_stream stream);
 /* gscale_dev: optional device fp32 scalar multiplied into gscale (the upstream d loss, read without a host sync).
  * lse: optional, the lse_out of the matching forward call; with it (s = 2 | 4) the softmax is not re-normalised:
- * one thread per low-res pixel gathers exp(z - lse) - onehot over the (2s)^2 high-res pixels that read it. */
+ * one thread per low-res pixel gathers exp(z - lse) - onehot over the (2s)^2 high-res pixels that read it.
+ * dlo may be NULL on that path in bf16 mode when only the T copy dlo_t is wanted (the fused head backward reads nothing else). */
 int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, const float* lse, float gscale, const float* gscale_dev,
                  float* dlo, void* dlo_t, int B, int h, int w, int C, int ldc, int s, int ignore_index, int dtype,
                  s4f_stream stream);

@@ -1158,7 +1158,17 @@ __global__ __launch_bounds__(256) void upce_bwd_lse_kernel(const float* __restri
   constexpr int R = 2 * S;
   constexpr bool EXACT = sizeof(T) == 4;
   constexpr float kL2E = 1.4426950408889634f;
-  __shared__ float oh[32 * 256];
+  // round 3: the 18 x 18 low-res neighbourhood of the block's 16 x 16 pixels is staged in LDS with coalesced 16-B loads (a
+  // thread reading its nine neighbours straight from global touches 64 different 128-B lines per wave-instruction: the
+  // kernel was bound by line requests, 3.4 x its VALU time); pixel stride 36 floats keeps the ds_read_b128 groups (nearly)
+  // conflict-free.  Behind it the private one-hot columns.
+  constexpr int HW = 18;
+  const int C4 = (C + 3) >> 2;
+  const int HS = 4 * C4;                              // floats per staged pixel: the class groups, no padding (2-way bank conflicts on the
+                                                      // neighbour reads are cheaper than the third resident block the padding would cost)
+  extern __shared__ __attribute__((aligned(16))) char upce_smem[];
+  float* halo = reinterpret_cast<float*>(upce_smem);
+  float* oh = halo + HW * HW * HS;                    // [max(C, 4 * C4 - 2)][256]: one-hot sums, then rows 4 c4, 4 c4 + 1 = staged T output
   const int H = h * S, W = w * S;
   const int tiles_x = (w + 15) >> 4, tiles_y = (h + 15) >> 4;
   int bid = blockIdx.x;
@@ -1166,11 +1176,28 @@ __global__ __launch_bounds__(256) void upce_bwd_lse_kernel(const float* __restri
   const int ty = bid % tiles_y;
   const int b = bid / tiles_y;
   const int tid = threadIdx.x;
-  const int j = tx * 16 + (tid & 15), i = ty * 16 + (tid >> 4);
-  if (i >= h || j >= w) return;                       // no block-level synchronisation below
+  const int lix = tid & 15, liy = tid >> 4;
+  const int j = tx * 16 + lix, i = ty * 16 + liy;
+  {
+    const int nch = C4;                                // only the class groups are staged
+    for (int idx = tid; idx < HW * HW * nch; idx += 256) {
+      const int cell = idx / nch, c = idx - cell * nch;
+      const int hy = cell / HW, hx = cell - hy * HW;
+      const int py = min(max(ty * 16 - 1 + hy, 0), h - 1), px = min(max(tx * 16 - 1 + hx, 0), w - 1);
+      f32x4 v = *reinterpret_cast<const f32x4*>(lo + (((long)b * h + py) * w + px) * ldc + c * 4);
+      if (!EXACT) v *= kL2E;                             // log2 units once per staged value, not once per use
+      *reinterpret_cast<f32x4*>(halo + cell * HS + c * 4) = v;
+    }
+  }
+  for (int c = 0; c < C; ++c) oh[c * 256 + tid] = 0.f;
+  __syncthreads();
+  const bool valid = i < h && j < w;
+  // bf16 copy: group c4's four values leave as two dwords in the one-hot rows 4 c4, 4 c4 + 1 of this thread's column (just
+  // consumed, private), and the block writes the 64-B rows of its pixels together at the end: 16 B per lane, coalesced
+  constexpr bool STAGE_T = sizeof(T) == 2;
+  const long p = ((long)b * h + min(i, h - 1)) * w + min(j, w - 1);
+  if (valid) {
   if (gscale_dev) gscale *= *gscale_dev;
-#pragma unroll
-  for (int c = 0; c < 32; ++c) oh[c * 256 + tid] = 0.f;
   const int oy0 = S * i - S / 2, ox0 = S * j - S / 2;
   float wy[R], wx[R];
 #pragma unroll
@@ -1179,70 +1206,71 @@ __global__ __launch_bounds__(256) void upce_bwd_lse_kernel(const float* __restri
     wy[k] = (oy >= 0 && oy < H) ? lerp_w(oy, i, S, h) : 0.f;
     wx[k] = (ox >= 0 && ox < W) ? lerp_w(ox, j, S, w) : 0.f;
   }
+  // labels and logsumexp of the (2S)^2 window: unconditional loads at clamped coordinates (all in flight together; a load
+  // under a per-sample branch made every sample wait for its own round trip), the weight decides what counts
+  int labv[R][R];
+  float lsv[R][R];
+#pragma unroll
+  for (int k = 0; k < R; ++k)
+#pragma unroll
+    for (int l = 0; l < R; ++l) {
+      const long idx = ((long)b * H + min(max(oy0 + k, 0), H - 1)) * W + min(max(ox0 + l, 0), W - 1);
+      labv[k][l] = labels[idx];
+      lsv[k][l] = lse[idx];
+    }
   float wg[R][R], ls[R][R];
 #pragma unroll
   for (int k = 0; k < R; ++k)
 #pragma unroll
     for (int l = 0; l < R; ++l) {
       const float wgt = wy[k] * wx[l];
-      float g = 0.f, lv = 1e30f;
-      if (wgt != 0.f) {
-        const long idx = ((long)b * H + (oy0 + k)) * W + (ox0 + l);
-        const int lab = labels[idx];
-        if (lab != ignore && lab < C) {
-          g = wgt * gscale;
-          lv = EXACT ? lse[idx] : lse[idx] * kL2E;
-          oh[lab * 256 + tid] += g;
-        }
-      }
+      const int lab = labv[k][l];
+      const bool live = wgt != 0.f && lab != ignore && lab < C;
+      const float g = live ? wgt * gscale : 0.f;
+      if (live) oh[lab * 256 + tid] += g;
       wg[k][l] = g;
-      ls[k][l] = lv;
+      ls[k][l] = live ? (EXACT ? lsv[k][l] : lsv[k][l] * kL2E) : 1e30f;
     }
-  const int rr[3] = {max(i - 1, 0), i, min(i + 1, h - 1)};
-  const int cc[3] = {max(j - 1, 0), j, min(j + 1, w - 1)};
-  const float* P[3][3];
-#pragma unroll
-  for (int m = 0; m < 3; ++m)
-#pragma unroll
-    for (int n = 0; n < 3; ++n) P[m][n] = lo + (((long)b * h + rr[m]) * w + cc[n]) * ldc;
-  const long p = ((long)b * h + i) * w + j;
-  // the nine neighbour chunks of class group c4 + 1 are in flight while group c4 is computed (the loop is not unrolled:
-  // without the prefetch every group pays a full global-load latency before its ~500 VALU instructions)
+  // halo cell (liy + m, lix + n) = pixel (clamp(i - 1 + m), clamp(j - 1 + n))
+  const float* P0 = halo + (liy * HW + lix) * HS;
   f32x4 Ln[3][3];
 #pragma unroll
   for (int m = 0; m < 3; ++m)
 #pragma unroll
-    for (int n = 0; n < 3; ++n) Ln[m][n] = *reinterpret_cast<const f32x4*>(P[m][n]);
+    for (int n = 0; n < 3; ++n) Ln[m][n] = *reinterpret_cast<const f32x4*>(P0 + (m * HW + n) * HS);
 #pragma unroll 1
-  for (int c4 = 0; c4 < kMaxC / 4; ++c4) {
-    if (c4 * 4 >= ldc) break;
+  for (int c4 = 0; c4 < C4; ++c4) {
     f32x4 out = {0.f, 0.f, 0.f, 0.f};
-    if (c4 * 4 < C) {
+    {
       f32x4 L[3][3];
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int n = 0; n < 3; ++n) L[m][n] = Ln[m][n];
-      if ((c4 + 1) * 4 < C) {
+      if (c4 + 1 < C4) {
 #pragma unroll
         for (int m = 0; m < 3; ++m)
 #pragma unroll
-          for (int n = 0; n < 3; ++n) Ln[m][n] = *reinterpret_cast<const f32x4*>(P[m][n] + (c4 + 1) * 4);
+          for (int n = 0; n < 3; ++n) Ln[m][n] = *reinterpret_cast<const f32x4*>(P0 + (m * HW + n) * HS + (c4 + 1) * 4);
       }
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        // separable bilinear: along x for the three neighbour rows, then along y; explicit fma (the file is built with
+        // -ffp-contract=off: sub + mul + add per sample made this kernel VALU-bound at twice the necessary issue count)
         float xr[3][R];
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
-          const float a0 = EXACT ? L[m][0][e] : L[m][0][e] * kL2E;
-          const float a1 = EXACT ? L[m][1][e] : L[m][1][e] * kL2E;
-          const float a2 = EXACT ? L[m][2][e] : L[m][2][e] * kL2E;
+          const float a0 = L[m][0][e], a1 = L[m][1][e], a2 = L[m][2][e];
+          const float d0 = a1 - a0, d1 = a2 - a1;
 #pragma unroll
           for (int l = 0; l < R; ++l) {
             const float f = ((l < S ? l : l - S) + 0.5f) / S;
-            xr[m][l] = l < S ? a0 + f * (a1 - a0) : a1 + f * (a2 - a1);
+            xr[m][l] = l < S ? __builtin_fmaf(f, d0, a0) : __builtin_fmaf(f, d1, a1);
           }
         }
+        float dv[2][R];
+#pragma unroll
+        for (int l = 0; l < R; ++l) { dv[0][l] = xr[1][l] - xr[0][l]; dv[1][l] = xr[2][l] - xr[1][l]; }
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
@@ -1250,19 +1278,51 @@ __global__ __launch_bounds__(256) void upce_bwd_lse_kernel(const float* __restri
           const int m0 = k < S ? 0 : 1;
 #pragma unroll
           for (int l = 0; l < R; ++l) {
-            const float z = xr[m0][l] + f * (xr[m0 + 1][l] - xr[m0][l]);
+            const float z = __builtin_fmaf(f, dv[m0][l], xr[m0][l]);
             const float pr = EXACT ? expf(z - ls[k][l]) : __builtin_amdgcn_exp2f(z - ls[k][l]);
-            acc += wg[k][l] * pr;
+            acc = __builtin_fmaf(wg[k][l], pr, acc);
           }
         }
         const int c = c4 * 4 + e;
         out[e] = c < C ? acc - oh[c * 256 + tid] : 0.f;
       }
     }
-    *reinterpret_cast<f32x4*>(dlo + p * ldc + c4 * 4) = out;
+    if (dlo) *reinterpret_cast<f32x4*>(dlo + p * ldc + c4 * 4) = out;
     if (dlo_t) {
+      if constexpr (STAGE_T) {
+        union { bf16x4 v; float f[2]; } o4;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) dlo_t[p * ldc + c4 * 4 + e] = from_f32<T>(out[e]);
+        for (int e = 0; e < 4; ++e) o4.v[e] = (bf16_t)out[e];
+        oh[(4 * c4) * 256 + tid] = o4.f[0];
+        oh[(4 * c4 + 1) * 256 + tid] = o4.f[1];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dlo_t[p * ldc + c4 * 4 + e] = from_f32<T>(out[e]);
+      }
+    }
+  }
+  // columns beyond the classes: zeros
+  for (int c4 = C4; c4 * 4 < ldc; ++c4) {
+    if (dlo) *reinterpret_cast<f32x4*>(dlo + p * ldc + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (dlo_t && !STAGE_T) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dlo_t[p * ldc + c4 * 4 + e] = from_f32<T>(0.f);
+    }
+  }
+  }
+  if constexpr (STAGE_T) {
+    if (dlo_t) {
+      __syncthreads();
+      const int nch = ldc >> 3;                          // 16-B chunks per pixel of the bf16 copy
+      for (int idx = tid; idx < 256 * nch; idx += 256) {
+        const int q = idx / nch, k = idx - q * nch;      // pixel of the tile, chunk (class groups 2 k, 2 k + 1)
+        const int qi = ty * 16 + (q >> 4), qj = tx * 16 + (q & 15);
+        if (qi >= h || qj >= w) continue;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (2 * k < C4) { v[0] = oh[(8 * k) * 256 + q]; v[1] = oh[(8 * k + 1) * 256 + q]; }
+        if (2 * k + 1 < C4) { v[2] = oh[(8 * k + 4) * 256 + q]; v[3] = oh[(8 * k + 5) * 256 + q]; }
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(dlo_t) + ((((long)b * h + qi) * w + qj) * ldc + k * 8) * 2) = v;
+      }
     }
   }
 }
@@ -1701,17 +1761,27 @@ S4F_API int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, const fl
                          const float* gscale_dev, float* dlo, void* dlo_t, int B, int h, int w, int C, int ldc, int s,
                          int ignore_index, int dtype, s4f_stream stream) {
   DT_CHECK("s4f_upce_bwd");
-  S4F_CHECK(logits_lo && labels && dlo, "s4f_upce_bwd: null pointer");
+  S4F_CHECK(logits_lo && labels && (dlo || (dlo_t && dtype == S4F_BF16 && lse && (s == 2 || s == 4))), "s4f_upce_bwd: null pointer");
   LOGIT_CHECK("s4f_upce_bwd");
-  if (lse && (s == 2 || s == 4)) {
+  if (lse && (s == 2 || s == 4) && ldc <= 32 && ldc % 4 == 0) {
     const int nblk = B * ceil_div(h, 16) * ceil_div(w, 16);
     hipStream_t st = (hipStream_t)stream;
+    const int c4n = ceil_div(C, 4);
+    const size_t shm = (size_t)(18 * 18 * 4 * c4n + (C > 4 * c4n - 2 ? C : 4 * c4n - 2) * 256) * sizeof(float);   // halo + one-hot columns: 53.6 KB at 21 classes = three blocks per CU
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute((const void*)upce_bwd_lse_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      hipFuncSetAttribute((const void*)upce_bwd_lse_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      hipFuncSetAttribute((const void*)upce_bwd_lse_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      hipFuncSetAttribute((const void*)upce_bwd_lse_kernel<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      attr_set = true;
+    }
     if (dtype == S4F_BF16) {
-      if (s == 2) hipLaunchKernelGGL((upce_bwd_lse_kernel<bf16_t, 2>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, ignore_index);
-      else hipLaunchKernelGGL((upce_bwd_lse_kernel<bf16_t, 4>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, ignore_index);
+      if (s == 2) hipLaunchKernelGGL((upce_bwd_lse_kernel<bf16_t, 2>), dim3(nblk), dim3(256), shm, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, ignore_index);
+      else hipLaunchKernelGGL((upce_bwd_lse_kernel<bf16_t, 4>), dim3(nblk), dim3(256), shm, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, ignore_index);
     } else {
-      if (s == 2) hipLaunchKernelGGL((upce_bwd_lse_kernel<float, 2>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (float*)dlo_t, B, h, w, C, ldc, ignore_index);
-      else hipLaunchKernelGGL((upce_bwd_lse_kernel<float, 4>), dim3(nblk), dim3(256), 0, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (float*)dlo_t, B, h, w, C, ldc, ignore_index);
+      if (s == 2) hipLaunchKernelGGL((upce_bwd_lse_kernel<float, 2>), dim3(nblk), dim3(256), shm, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (float*)dlo_t, B, h, w, C, ldc, ignore_index);
+      else hipLaunchKernelGGL((upce_bwd_lse_kernel<float, 4>), dim3(nblk), dim3(256), shm, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (float*)dlo_t, B, h, w, C, ldc, ignore_index);
     }
     S4F_LAUNCH_CHECK();
     return 0;

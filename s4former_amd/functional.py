@@ -758,6 +758,15 @@ def _head_forward_gen(tokens, hp, store, training, save, ex):
     return logits, (Bn, h, w), sv
 
 
+def _fuse_cls_grad(sv, hp):
+    """is the input gradient of conv_seg recomputed inside the last stage's two BN backward passes (cls_bn_bwd_stats / _apply)?
+    Then nothing reads the fp32 gradient of the low-res logits, only its T copy."""
+    last = sv['stages'][-1]
+    cin = sv['feat'].shape[1]
+    return bool(FUSE_CLS_GRAD and SKIP_MASKED_COPY and last['s'] == 1 and last['Cc'] == cin and cin in (64, 128, 192, 256)
+                and hp['num_classes'] <= 32 and LOGIT_LD >= 32)
+
+
 def head_backward(dlo, dlo_t, sv, hp, store):
     """gradients of everything upstream of the low-res logits; returns d tokens (fp32 [B, T+1, E])."""
     return _run_one(_head_backward_gen, dlo, dlo_t, sv, hp, store, world=_world() if hp['sync_bn'] else 1)
@@ -780,9 +789,7 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
     # without upsample: its two BN backward passes recompute it from the 32-column dlo rows on the matrix cores
     # (s4f_cls_bn_bwd_stats / _apply; FUSE_CLS_GRAD=0: the GEMM + the generic passes); the statistics pass also leaves the
     # conv_seg bias gradient (column sums of dlo)
-    last = sv['stages'][-1]
-    fuse_cls = FUSE_CLS_GRAD and SKIP_MASKED_COPY and last['s'] == 1 and last['Cc'] == cin and cin in (64, 128, 192, 256) \
-        and ncls <= 32 and LOGIT_LD >= 32
+    fuse_cls = _fuse_cls_grad(sv, hp)
     dcur = None
     if not fuse_cls:
         K.colsum(dlo, LOGIT_LD, Mp, ncls, store.grad_phys(hp['seg_b']), F32)
@@ -893,8 +900,10 @@ class HeadLossFn(Function):
         labels, k, Bn, h, w, s = ctx.meta
         code = store.dtype
         logits = sv['logits']
-        dlo = torch.empty_like(logits)
         dlo_t = torch.empty(logits.shape, device=logits.device, dtype=torch.bfloat16) if code == BF16 else None
+        # bf16 mode with the fused conv_seg gradient: nothing reads the fp32 gradient of the logits, only its T copy
+        t_only = dlo_t is not None and ctx.lse is not None and _fuse_cls_grad(sv, hp) and not (ctx.ncr_lo is not None and dncr is not None)
+        dlo = None if t_only else torch.empty_like(logits)
         gdev = dloss.detach().reshape(1).to(torch.float32).contiguous()
         K.upce_bwd(logits, labels, k, dlo, dlo_t, Bn, h, w, hp['num_classes'], LOGIT_LD, s, code, hp['ignore_index'],
                    gscale_dev=gdev, lse=ctx.lse)

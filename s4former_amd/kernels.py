@@ -556,7 +556,9 @@ def upce_bwd(logits_lo, labels, gscale, dlo, dlo_t, B, h, w, C, ldc, s, dtype, i
              lse=None):
     _chk_f32(logits_lo, 'upce_bwd logits'); _need(logits_lo, B * h * w * ldc, 'upce_bwd logits')
     _chk_u8(labels, B * h * s * w * s, 'upce_bwd labels')
-    _chk_f32(dlo, 'upce_bwd dlo'); _need(dlo, B * h * w * ldc, 'upce_bwd dlo')
+    if dlo is None and not (dlo_t is not None and dtype == BF16 and lse is not None and s in (2, 4)):
+        raise S4FError('upce_bwd: the fp32 gradient may be omitted only on the bf16 logsumexp path (T copy given)')
+    _chk_f32(dlo, 'upce_bwd dlo'); _need(dlo, B * h * w * ldc if dlo is not None else 0, 'upce_bwd dlo')
     _chk_dtype(dlo_t, dtype, 'upce_bwd dlo_t'); _need(dlo_t, B * h * w * ldc if dlo_t is not None else 0, 'upce_bwd dlo_t')
     _chk_f32(gscale_dev, 'upce_bwd gscale_dev'); _need(gscale_dev, 1 if gscale_dev is not None else 0, 'upce_bwd gscale_dev')
     _chk_f32(lse, 'upce_bwd lse'); _need(lse, B * h * s * w * s if lse is not None else 0, 'upce_bwd lse')

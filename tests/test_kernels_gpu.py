@@ -515,6 +515,13 @@ def test_upsample_ce(K, s, C):
             check(dlo2[..., :C], to_nhwc(lor.grad), 0, f'upsample+CE dlogits from lse (dtype {code})', tol=tol)
             assert float(dlo2[..., C:].abs().max()) == 0.0
             check(dlo2_t[..., :C].float(), to_nhwc(lor.grad), 1, 'upsample+CE dlogits from lse, T copy', tol=1e-2)
+            if code:
+                # the fused head backward wants the T copy only: same bits, and the padding columns are zero
+                only_t = torch.full((B, h, w, ldc), 7.0, device='cuda', dtype=torch.bfloat16)
+                K.upce_bwd(lod, labd, 0.8 / numel, None, only_t, B, h, w, C, ldc, s, code,
+                           gscale_dev=torch.full((1,), 0.5, device='cuda'), lse=lse)
+                assert torch.equal(only_t, dlo2_t), 'T copy without the fp32 gradient differs'
+                assert float(only_t[..., C:].float().abs().max()) == 0.0
     # all-ignored image -> loss 0, grad 0
     lab0 = torch.full((B, h * s, w * s), 255, dtype=torch.uint8)
     ls.zero_()
