@@ -239,6 +239,8 @@ int s4f_bn_param_grads(const float* sums_local, float* dgamma, float* dbeta, int
  * back.  y T [npix, C] is the conv output (BN input), scale / shift the folded BN affine (ReLU mask: y*scale+shift > 0).
  *   stats: sums[0:C] += sum_p g, sums[C:2C] += sum_p g * xhat  with g = d * mask           (= s4f_bn_relu_up_bwd, s = 1);
  *          seg_b_grad (optional, fp32 [ncls]) += column sums of dlo, the conv_seg bias gradient, from the rows already loaded
+ *          seg_w_grad (optional, fp32 [ncls, C]) += dlo^T relu(y scale + shift), the conv_seg weight gradient
+ *          (decode_head.py:318-327 backward): the activation is rebuilt by this pass anyway, so the forward need not store it
  *   apply: dy = gamma * rstd * (g - sum_g/count - xhat * sum_gx/count)                      (= s4f_bn_bwd_apply)
  * C in {64, 128, 192, 256}, ncls <= 32 <= ld_dlo. */
 /* forward of the same stage in one pass over y: logits[p][k] = seg_b[k] + sum_c relu(y[p][c] scale[c] + shift[c]) seg_w[k][c]
@@ -247,8 +249,8 @@ int s4f_bn_param_grads(const float* sums_local, float* dgamma, float* dbeta, int
 int s4f_bn_relu_cls_fwd(const void* y, const float* scale, const float* shift, const void* seg_w, const float* seg_b,
                         float* logits, int ld_logits, void* feat, int64_t npix, int C, int ncls, int dtype, s4f_stream stream);
 int s4f_cls_bn_bwd_stats(const void* dlo, int ld_dlo, const void* seg_w, const void* y, const float* scale,
-                         const float* shift, const float* mean, const float* rstd, float* sums, float* seg_b_grad, int64_t npix,
-                         int C, int ncls, int dtype, s4f_stream stream);
+                         const float* shift, const float* mean, const float* rstd, float* sums, float* seg_b_grad,
+                         float* seg_w_grad, int64_t npix, int C, int ncls, int dtype, s4f_stream stream);
 int s4f_cls_bn_bwd_apply(const void* dlo, int ld_dlo, const void* seg_w, const void* y, const float* scale,
                          const float* shift, const float* mean, const float* rstd, const float* gamma, const float* sums,
                          double count, void* dy, int64_t npix, int C, int ncls, int dtype, s4f_stream stream);

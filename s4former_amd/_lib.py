@@ -86,7 +86,7 @@ _SIGS = {
     's4f_bn_bwd_apply': [c_void_p] * 6 + [c_double, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p],
     's4f_bn_param_grads': [c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     's4f_bn_relu_cls_fwd': [c_void_p] * 6 + [c_int, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
-    's4f_cls_bn_bwd_stats': [c_void_p, c_int] + [c_void_p] * 8 + [c_int64, c_int, c_int, c_int, c_void_p],
+    's4f_cls_bn_bwd_stats': [c_void_p, c_int] + [c_void_p] * 9 + [c_int64, c_int, c_int, c_int, c_void_p],
     's4f_cls_bn_bwd_apply': [c_void_p, c_int] + [c_void_p] * 8 + [c_double, c_void_p, c_int64, c_int, c_int, c_int, c_void_p],
     's4f_upce_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     's4f_upce_bwd': [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

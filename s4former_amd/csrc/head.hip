@@ -627,11 +627,25 @@ __global__ __launch_bounds__(256) void cls_bn_bwd_stats_kernel(const T* __restri
                                                                const T* __restrict__ y, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, float* __restrict__ sums,
-                                                               float* __restrict__ dbias, long npix, int C, int ncls) {
+                                                               float* __restrict__ dbias, float* __restrict__ dW, long npix, int C,
+                                                               int ncls) {
   constexpr int UG = 2;                  // pixel groups in flight per wave
   ClsGrad<T> cg;
   cg.init(W, C, ncls, ld);
   const int g = cg.g, li = cg.li, cw = cg.cw;
+  // round 3: the conv_seg WEIGHT gradient dW[c][k] += sum_p dlo[p][c] u[p][k], u = relu(scale y + shift) = the activation this
+  // pass reconstructs anyway.  The pass holds (pixel, 8 channels) per lane; the product contracts over pixels, so the 32 pixels
+  // of an iteration go through a wave-private LDS tile and come back pixel-major (transposed reads) as MFMA operands:
+  // 8 MFMAs per 32 pixels and wave.  The forward then never writes u and no GEMM re-reads it (268 MB each at 8 x 256^2).
+  constexpr int SU = 64 * (int)sizeof(T) + 16, SD = 32 * (int)sizeof(T) + 16;     // row strides of the u / dlo tiles (bytes)
+  __shared__ __attribute__((aligned(16))) char wtile[4 * 32 * (SU + SD)];
+  char* ut = wtile + (threadIdx.x >> 6) * 32 * (SU + SD);
+  char* dt = ut + 32 * SU;
+  f32x4 wacc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   float sc[2][8], sh[2][8], mu[2][8], rs[2][8], sg[2][8], sgx[2][8];
 #pragma unroll
   for (int u = 0; u < 2; ++u)
@@ -669,14 +683,46 @@ __global__ __launch_bounds__(256) void cls_bn_bwd_stats_kernel(const T* __restri
       for (int u = 0; u < 2; ++u) {
         float d[8];
         cg.grad(fb[q], u, d);
+        float act[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float gg = (yv[q][u][e] * sc[u][e] + sh[u][e] > 0.f) ? d[e] : 0.f;
+          const float a = yv[q][u][e] * sc[u][e] + sh[u][e];
+          const float gg = (a > 0.f) ? d[e] : 0.f;
+          act[e] = a > 0.f ? a : 0.f;
           sg[u][e] += gg;
           sgx[u][e] += gg * (yv[q][u][e] - mu[u][e]) * rs[u][e];
         }
+        if (dW) store8<T>(reinterpret_cast<T*>(ut + (16 * q + li) * SU) + 32 * u + 8 * g, act);
+      }
+      if (dW) {
+        float dv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dv[j] = to_f32<T>(fb[q].v[j]);
+        store8<T>(reinterpret_cast<T*>(dt + (16 * q + li) * SD) + 8 * g, dv);
       }
     }
+    if (dW) {                                            // block-uniform; the tiles are private to the wave
+      Frag<T> fd[2], fu[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) lds_read_tr(fd[i], dt, SD, 0, 16 * i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds_read_tr(fu[j], ut, SU, 0, 16 * j);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wacc[i][j] = mma16(fd[i], fu[j], wacc[i][j]);
+    }
+  }
+  if (dW) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int cls = 16 * i + 4 * g + r;
+          if (cls < ncls) atomicAdd(dW + (long)cls * C + cw + 16 * j + li, wacc[i][j][r]);
+        }
   }
   if (do_bias) {
 #pragma unroll
@@ -1668,14 +1714,15 @@ static int cls_bn_check(const char* who, const void* dlo, const void* w, const v
 
 S4F_API int s4f_cls_bn_bwd_stats(const void* dlo, int ld_dlo, const void* seg_w, const void* y, const float* scale,
                                  const float* shift, const float* mean, const float* rstd, float* sums, float* seg_b_grad,
-                                 int64_t npix, int C, int ncls, int dtype, s4f_stream stream) {
+                                 float* seg_w_grad, int64_t npix, int C, int ncls, int dtype, s4f_stream stream) {
   DT_CHECK("s4f_cls_bn_bwd_stats");
   if (int rc = cls_bn_check("s4f_cls_bn_bwd_stats", dlo, seg_w, y, npix, C, ncls, ld_dlo)) return rc;
   S4F_CHECK(scale && shift && mean && rstd && sums, "s4f_cls_bn_bwd_stats: null pointer");
   int grid = ceil_div(ceil_div(npix, 16), 32);        // >= 32 pixel groups per block: the 2 C atomics at the end of a block are
-  if (grid > 512) grid = 512;                         // what this pass waits for (1024 blocks of 8 groups: 43 instead of 30 us at 8 x 128 x 128)
-  if (dtype == S4F_BF16) hipLaunchKernelGGL(cls_bn_bwd_stats_kernel<bf16_t>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const bf16_t*)dlo, ld_dlo, (const bf16_t*)seg_w, (const bf16_t*)y, scale, shift, mean, rstd, sums, seg_b_grad, (long)npix, C, ncls);
-  else hipLaunchKernelGGL(cls_bn_bwd_stats_kernel<float>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const float*)dlo, ld_dlo, (const float*)seg_w, (const float*)y, scale, shift, mean, rstd, sums, seg_b_grad, (long)npix, C, ncls);
+  if (grid > 512) grid = 512;                         // what this pass waits for (1024 blocks of 8 groups: 43 instead of 30 us at 8 x 128 x 128;
+                                                      // round 3: caps of 512 - 4096 at 8 x 256 x 256: 83 - 95 us, no trend)
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(cls_bn_bwd_stats_kernel<bf16_t>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const bf16_t*)dlo, ld_dlo, (const bf16_t*)seg_w, (const bf16_t*)y, scale, shift, mean, rstd, sums, seg_b_grad, seg_w_grad, (long)npix, C, ncls);
+  else hipLaunchKernelGGL(cls_bn_bwd_stats_kernel<float>, dim3(grid), dim3(C), 0, (hipStream_t)stream, (const float*)dlo, ld_dlo, (const float*)seg_w, (const float*)y, scale, shift, mean, rstd, sums, seg_b_grad, seg_w_grad, (long)npix, C, ncls);
   S4F_LAUNCH_CHECK();
   return 0;
 }

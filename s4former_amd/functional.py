@@ -23,6 +23,7 @@ from ._lib import BF16, F32, S4FError
 
 SKIP_MASKED_COPY = os.environ.get('S4F_SKIP_MASKED_COPY', '1') != '0'     # A/B switch of head_backward's s = 1 stages
 FUSE_CLS_FWD = os.environ.get('S4F_FUSE_CLS_FWD', '1') != '0'             # A/B switch: BN + ReLU + conv_seg forward in one pass
+FUSE_CLS_WGRAD = os.environ.get('S4F_FUSE_CLS_WGRAD', '1') != '0'         # A/B switch: conv_seg weight gradient inside the BN statistics pass (no stored activation)
 FUSE_CLS_GRAD = os.environ.get('S4F_FUSE_CLS_GRAD', '1') != '0'           # A/B switch: conv_seg input gradient inside the BN backward passes
 LOGIT_LD = 32   # channel stride of the low-resolution logits buffers (>= num_classes, multiple of 8)
 
@@ -736,7 +737,10 @@ def _head_forward_gen(tokens, hp, store, training, save, ex):
             # last stage: BN affine + ReLU + conv_seg in ONE pass over y; the activation is written only if a backward
             # pass will need it (the conv_seg weight gradient), never on the teacher / inference path
             logits = torch.empty(Mp, LOGIT_LD, device=dev)
-            u = torch.empty(Mp, Cc, device=dev, dtype=T) if save else None
+            # ... and not even then when the backward's statistics pass forms the conv_seg weight gradient from the activation
+            # it rebuilds (FUSE_CLS_WGRAD)
+            keep_u = save and not (FUSE_CLS_WGRAD and _fuse_cls_ok(s, Cc, hp['num_classes']))
+            u = torch.empty(Mp, Cc, device=dev, dtype=T) if keep_u else None
             K.bn_relu_cls_fwd(y, scale, shift, store.shadow(hp['seg_w']), store.phys(hp['seg_b']), logits, LOGIT_LD, u, Mp, Cc,
                               hp['num_classes'], code)
         else:
@@ -758,13 +762,16 @@ def _head_forward_gen(tokens, hp, store, training, save, ex):
     return logits, (Bn, h, w), sv
 
 
+def _fuse_cls_ok(s_last, Cc, ncls):
+    return bool(FUSE_CLS_GRAD and SKIP_MASKED_COPY and s_last == 1 and Cc in (64, 128, 192, 256) and ncls <= 32 and LOGIT_LD >= 32)
+
+
 def _fuse_cls_grad(sv, hp):
     """is the input gradient of conv_seg recomputed inside the last stage's two BN backward passes (cls_bn_bwd_stats / _apply)?
-    Then nothing reads the fp32 gradient of the low-res logits, only its T copy."""
+    Then nothing reads the fp32 gradient of the low-res logits, only its T copy - and (FUSE_CLS_WGRAD) the statistics pass also
+    forms the conv_seg WEIGHT gradient from the activation it rebuilds, so that the forward does not store it (sv['feat'] None)."""
     last = sv['stages'][-1]
-    cin = sv['feat'].shape[1]
-    return bool(FUSE_CLS_GRAD and SKIP_MASKED_COPY and last['s'] == 1 and last['Cc'] == cin and cin in (64, 128, 192, 256)
-                and hp['num_classes'] <= 32 and LOGIT_LD >= 32)
+    return _fuse_cls_ok(last['s'], last['Cc'], hp['num_classes'])
 
 
 def head_backward(dlo, dlo_t, sv, hp, store):
@@ -780,16 +787,21 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
     dev = tokens.device
     ncls = hp['num_classes']
     feat = sv['feat']
-    cin = feat.shape[1]
-    Mp = feat.shape[0]
+    last = sv['stages'][-1]
+    cin = last['Cc']
+    Mp = Bn * last['h'] * last['s'] * last['w'] * last['s']
     # conv_seg: dW[ncls, cin] += dlo^T feat ; db += colsum(dlo) ; dfeat = dlo W
-    K.gemm(dlo_t, feat, ncls, cin, Mp, LOGIT_LD, cin, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=store.grad_phys(hp['seg_w']),
-           ldo_f32=cin, atomic=True, splitk=_splitk(_tiles(ncls, cin), _nk(Mp, code), target=1024))
+    wgrad_in_stats = feat is None
+    if not wgrad_in_stats:
+        K.gemm(dlo_t, feat, ncls, cin, Mp, LOGIT_LD, cin, code, a_mode=K.OP_K, b_mode=K.OP_K, out_f32=store.grad_phys(hp['seg_w']),
+               ldo_f32=cin, atomic=True, splitk=_splitk(_tiles(ncls, cin), _nk(Mp, code), target=1024))
     # The input gradient of conv_seg, dfeat = dlo W, is not materialised when the stage below is the usual conv -> BN -> ReLU
     # without upsample: its two BN backward passes recompute it from the 32-column dlo rows on the matrix cores
     # (s4f_cls_bn_bwd_stats / _apply; FUSE_CLS_GRAD=0: the GEMM + the generic passes); the statistics pass also leaves the
     # conv_seg bias gradient (column sums of dlo)
     fuse_cls = _fuse_cls_grad(sv, hp)
+    if wgrad_in_stats and not fuse_cls:
+        raise S4FError('head backward: the forward did not keep the last activation but the fused conv_seg gradient is off')
     dcur = None
     if not fuse_cls:
         K.colsum(dlo, LOGIT_LD, Mp, ncls, store.grad_phys(hp['seg_b']), F32)
@@ -804,7 +816,8 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
         dy = torch.empty(Mk, Cc, device=dev, dtype=T)
         if dcur is None:
             K.cls_bn_bwd_stats(dlo_t, LOGIT_LD, store.shadow(hp['seg_w']), st['y'], st['scale'], st['shift'], st['mean'],
-                               st['rstd'], bsums, Mk, Cc, ncls, code, seg_b_grad=store.grad_phys(hp['seg_b']))
+                               st['rstd'], bsums, Mk, Cc, ncls, code, seg_b_grad=store.grad_phys(hp['seg_b']),
+                               seg_w_grad=store.grad_phys(hp['seg_w']) if wgrad_in_stats else None)
             K.bn_param_grads(bsums, store.grad_phys(cv['bn_w']), store.grad_phys(cv['bn_b']), Cc)
             yield                                            # the sums cross the ranks (lockstep heads: together)
             K.cls_bn_bwd_apply(dlo_t, LOGIT_LD, store.shadow(hp['seg_w']), st['y'], st['scale'], st['shift'], st['mean'],

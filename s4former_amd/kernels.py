@@ -513,14 +513,16 @@ def _cls_bn_common(what, dlo, ld_dlo, seg_w, y, npix, C, ncls, dtype, *per_chann
         _chk_f32(t, what); _need(t, C, what)
 
 
-def cls_bn_bwd_stats(dlo, ld_dlo, seg_w, y, scale, shift, mean, rstd, sums, npix, C, ncls, dtype, seg_b_grad=None):
+def cls_bn_bwd_stats(dlo, ld_dlo, seg_w, y, scale, shift, mean, rstd, sums, npix, C, ncls, dtype, seg_b_grad=None, seg_w_grad=None):
     """statistics pass of the last head stage's BN backward with the conv_seg input gradient recomputed from dlo (include/s4f.h);
-    seg_b_grad: += column sums of dlo (the conv_seg bias gradient)"""
+    seg_b_grad: += column sums of dlo (the conv_seg bias gradient); seg_w_grad (fp32 [ncls, C]): += dlo^T relu(y scale + shift),
+    the conv_seg weight gradient from the activation this pass rebuilds"""
     _cls_bn_common('cls_bn_bwd_stats', dlo, ld_dlo, seg_w, y, npix, C, ncls, dtype, scale, shift, mean, rstd)
     _chk_f32(sums, 'cls_bn_bwd_stats sums'); _need(sums, 2 * C, 'cls_bn_bwd_stats sums')
     _chk_f32(seg_b_grad, 'cls_bn_bwd_stats seg_b_grad'); _need(seg_b_grad, ncls if seg_b_grad is not None else 0, 'cls_bn_bwd_stats seg_b_grad')
+    _chk_f32(seg_w_grad, 'cls_bn_bwd_stats seg_w_grad'); _need(seg_w_grad, ncls * C if seg_w_grad is not None else 0, 'cls_bn_bwd_stats seg_w_grad')
     call('s4f_cls_bn_bwd_stats', p(dlo), ld_dlo, p(seg_w), p(y), p(scale), p(shift), p(mean), p(rstd), p(sums), p(seg_b_grad),
-         npix, C, ncls, dtype, stream())
+         p(seg_w_grad), npix, C, ncls, dtype, stream())
 
 
 def cls_bn_bwd_apply(dlo, ld_dlo, seg_w, y, scale, shift, mean, rstd, gamma, sums, count, dy, npix, C, ncls, dtype):

@@ -422,8 +422,15 @@ def test_cls_grad_inside_bn_backward(K, code, C, ncls, B, h, w):
     wd = dev(wseg, code)
     bsums = torch.zeros(2 * C, device='cuda')
     dbias = torch.full((ncls,), 0.5, device='cuda')
-    K.cls_bn_bwd_stats(dlo_d, LD, wd, xh, scale, shift, mean, rstd, bsums, npix, C, ncls, code, seg_b_grad=dbias)
+    dwseg = torch.full((ncls, C), 0.25, device='cuda')
+    K.cls_bn_bwd_stats(dlo_d, LD, wd, xh, scale, shift, mean, rstd, bsums, npix, C, ncls, code, seg_b_grad=dbias, seg_w_grad=dwseg)
     check(dbias, 0.5 + dlo.sum(0), code, 'conv_seg bias gradient from the statistics pass', tol=1e-5 if code == 0 else 1e-2)
+    # conv_seg weight gradient from the activation the pass rebuilds (no stored activation): dW = dlo^T relu(bn(x))
+    check(dwseg, 0.25 + dlo.t() @ to_nhwc(z.detach()).reshape(npix, C), code, 'conv_seg weight gradient from the statistics pass',
+          tol=1e-5 if code == 0 else 1e-2)
+    bs0 = torch.zeros(2 * C, device='cuda')
+    K.cls_bn_bwd_stats(dlo_d, LD, wd, xh, scale, shift, mean, rstd, bs0, npix, C, ncls, code)          # without it: same sums
+    assert torch.allclose(bs0, bsums, rtol=1e-5, atol=1e-6)
     dx = torch.empty(B, h, w, C, device='cuda', dtype=tdt(code))
     K.cls_bn_bwd_apply(dlo_d, LD, wd, xh, scale, shift, mean, rstd, dev(gamma), bsums, rows, dx, npix, C, ncls, code)
     dgam, dbet = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')

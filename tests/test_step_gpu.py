@@ -63,15 +63,19 @@ def run_product(model, opt, sched, meta, iters=2):
     return rec
 
 
+@pytest.mark.parametrize('which', ['all_off', 'wgrad_off'])
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-def test_unfused_head_paths_still_agree_with_the_golden(dtype, monkeypatch):
-    """the A/B switches of the head fusions (S4F_FUSE_CLS_FWD / _GRAD, S4F_FOLD_COLSUM) select the kernels that remain the
-    path for heads the fused kernels do not take (other channel counts, > 32 classes): those must stay correct too"""
+def test_unfused_head_paths_still_agree_with_the_golden(dtype, which, monkeypatch):
+    """the A/B switches of the head fusions (S4F_FUSE_CLS_FWD / _GRAD / _WGRAD, S4F_FOLD_COLSUM) select the kernels that remain
+    the path for heads the fused kernels do not take (other channel counts, > 32 classes): those must stay correct too"""
     import s4former_amd.functional as F_
     import s4former_amd.kernels as K_
-    monkeypatch.setattr(F_, 'FUSE_CLS_FWD', False)
-    monkeypatch.setattr(F_, 'FUSE_CLS_GRAD', False)
-    monkeypatch.setattr(K_, 'FOLD_COLSUM', False)
+    if which == 'all_off':
+        monkeypatch.setattr(F_, 'FUSE_CLS_FWD', False)
+        monkeypatch.setattr(F_, 'FUSE_CLS_GRAD', False)
+        monkeypatch.setattr(K_, 'FOLD_COLSUM', False)
+    else:
+        monkeypatch.setattr(F_, 'FUSE_CLS_WGRAD', False)      # stored activation + the separate conv_seg weight-gradient GEMM
     z, meta = load_gold('mt_pasa')
     model, opt, sched = build_product(meta, dtype)
     rec = run_product(model, opt, sched, meta, iters=1)
