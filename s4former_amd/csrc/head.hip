@@ -1857,11 +1857,100 @@ S4F_API int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, const fl
   return 0;
 }
 
+// round 3: the same arithmetic (sample_logits' four-weight form, bit for bit) with the block's 18 x 18 low-res neighbourhood
+// staged in LDS by coalesced loads: a thread of the kernel above reads four 128-B-strided logit rows per pixel, 32 cache lines
+// per wave-instruction, and was bound by line requests (93 us for 67 MB at 8 x 256^2; this one: see DESIGN.md).  One thread
+// per low-res pixel, S x S output pixels each.
+template <int S>
+__global__ __launch_bounds__(256) void up_pseudo_tiled_kernel(const float* __restrict__ lo, uint8_t* __restrict__ label_out,
+                                                              uint8_t* __restrict__ conf_out, unsigned long long* __restrict__ cnt,
+                                                              float th, int B, int h, int w, int C, int ldc) {
+  __shared__ float red[4];
+  extern __shared__ __attribute__((aligned(16))) char pseudo_smem[];
+  float* halo = reinterpret_cast<float*>(pseudo_smem);
+  const int C4 = (C + 3) >> 2;
+  const int HS = 4 * C4 + 4;
+  const int H = h * S, W = w * S;
+  const int tiles_x = (w + 15) >> 4, tiles_y = (h + 15) >> 4;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int tid = threadIdx.x;
+  const int j = tx * 16 + (tid & 15), i = ty * 16 + (tid >> 4);
+  const int y0 = ty * 16 - 1, x0 = tx * 16 - 1;             // low-res pixel of halo cell (0, 0)
+  for (int idx = tid; idx < 18 * 18 * C4; idx += 256) {
+    const int cell = idx / C4, c = idx - cell * C4;
+    const int hy = cell / 18, hx = cell - hy * 18;
+    const int py = min(max(y0 + hy, 0), h - 1), px = min(max(x0 + hx, 0), w - 1);
+    *reinterpret_cast<f32x4*>(halo + cell * HS + c * 4) =
+        *reinterpret_cast<const f32x4*>(lo + (((long)b * h + py) * w + px) * ldc + c * 4);
+  }
+  __syncthreads();
+  float nconf = 0.f;
+  if (i < h && j < w) {
+#pragma unroll
+    for (int r = 0; r < S; ++r) {
+      const int oy = S * i + r;
+      const Lerp ly = lerp_src(oy, S, h);
+#pragma unroll
+      for (int q = 0; q < S; ++q) {
+        const int ox = S * j + q;
+        const Lerp lx = lerp_src(ox, S, w);
+        // neighbours i0 / i1 lie in [i - 1, i + 1] (clamped at the border exactly as the halo is)
+        const float* p00 = halo + ((ly.i0 - y0) * 18 + (lx.i0 - x0)) * HS;
+        const float* p01 = halo + ((ly.i0 - y0) * 18 + (lx.i1 - x0)) * HS;
+        const float* p10 = halo + ((ly.i1 - y0) * 18 + (lx.i0 - x0)) * HS;
+        const float* p11 = halo + ((ly.i1 - y0) * 18 + (lx.i1 - x0)) * HS;
+        const float w00 = ly.l0 * lx.l0, w01 = ly.l0 * lx.l1, w10 = ly.l1 * lx.l0, w11 = ly.l1 * lx.l1;
+        float z[kMaxC];
+#pragma unroll
+        for (int c4 = 0; c4 < kMaxC / 4; ++c4) {
+          if (c4 < C4) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p00 + c4 * 4), bq = *reinterpret_cast<const f32x4*>(p01 + c4 * 4);
+            const f32x4 cq = *reinterpret_cast<const f32x4*>(p10 + c4 * 4), dq = *reinterpret_cast<const f32x4*>(p11 + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[c4 * 4 + e] = w00 * a[e] + w01 * bq[e] + w10 * cq[e] + w11 * dq[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[c4 * 4 + e] = 0.f;
+          }
+        }
+        float mx = -INFINITY;
+        int am = 0;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+          if (c < C && z[c] > mx) { mx = z[c]; am = c; }     // strict >: first index wins ties (torch.max)
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c)
+          if (c < C) se += expf(z[c] - mx);
+        const float pmax = 1.f / se;
+        const bool conf = pmax > th;
+        const long o = ((long)b * H + oy) * W + ox;
+        label_out[o] = conf ? (uint8_t)am : (uint8_t)255;
+        if (conf_out) conf_out[o] = conf ? 1 : 0;
+        nconf += conf ? 1.f : 0.f;
+      }
+    }
+  }
+  const float tot = block_sum_256(nconf, red);
+  if (threadIdx.x == 0 && cnt) atomicAdd(cnt, (unsigned long long)(tot + 0.5f));
+}
+
 S4F_API int s4f_up_pseudo_label(const float* logits_lo, uint8_t* label_out, uint8_t* conf_out, unsigned long long* conf_count,
                                 float th, int B, int h, int w, int C, int ldc, int s, s4f_stream stream) {
   S4F_CHECK(logits_lo && label_out, "s4f_up_pseudo_label: null pointer");
   LOGIT_CHECK("s4f_up_pseudo_label");
   const long total = (long)B * h * s * w * s;
+  if (s == 2 || s == 4) {
+    const int nblk = B * ceil_div(h, 16) * ceil_div(w, 16);
+    const size_t shm = (size_t)18 * 18 * (4 * ceil_div(C, 4) + 4) * sizeof(float);          // <= 46.7 KB
+    if (s == 2) hipLaunchKernelGGL(up_pseudo_tiled_kernel<2>, dim3(nblk), dim3(256), shm, (hipStream_t)stream, logits_lo, label_out, conf_out, conf_count, th, B, h, w, C, ldc);
+    else hipLaunchKernelGGL(up_pseudo_tiled_kernel<4>, dim3(nblk), dim3(256), shm, (hipStream_t)stream, logits_lo, label_out, conf_out, conf_count, th, B, h, w, C, ldc);
+    S4F_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(up_pseudo_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, logits_lo, label_out, conf_out, conf_count, th, B, h, w, C, ldc, s);
   S4F_LAUNCH_CHECK();
   return 0;

@@ -542,9 +542,9 @@ def test_upsample_ce(K, s, C):
     check(full, z.detach(), 0, 'upsampled logits NCHW', tol=1e-5)
 
 
-@pytest.mark.parametrize('s', [1, 2])
-def test_pseudo_label(K, s):
-    B, C, h, w, ldc = 2, 21, 16, 16, 32
+@pytest.mark.parametrize('s,h,w', [(1, 16, 16), (2, 16, 16), (2, 21, 9), (4, 19, 33)])
+def test_pseudo_label(K, s, h, w):
+    B, C, ldc = 2, 21, 32
     lo = rnd(B, C, h, w, seed=1, scale=4.0 if s == 1 else 12.0)   # logits ~ N(0, 4^2)
     if s == 1:
         lo[0, :, 0, 0] = 0.0                                 # all tie -> first index, p = 1/21
