@@ -870,6 +870,27 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
     return dtok
 
 
+HEAD_MARKS = None              # diagnostic (tools/exp/head_marks.py): list of (label, stream id, start event, end event, host t0, host t1)
+
+
+def _mark_begin(label):
+    if HEAD_MARKS is None:
+        return None
+    import time
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return (label, ev, time.perf_counter())
+
+
+def _mark_end(m):
+    if m is None:
+        return
+    import time
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    HEAD_MARKS.append((m[0], torch.cuda.current_stream().cuda_stream, m[1], ev, m[2], time.perf_counter()))
+
+
 class HeadLossFn(Function):
     """loss = loss_weight * mean_all_pixels CE(up_s(logits_lo), labels; ignore 255)   (Q5)
     With ncr_lo (the teacher's low-resolution logits of the same images): returns (loss, loss_ncr), loss_ncr = the negative
@@ -879,6 +900,7 @@ class HeadLossFn(Function):
     @staticmethod
     def forward(ctx, tokens, labels_u8, loss_weight, hp, store, ncr_lo, *prm):
         need_grad = any(ctx.needs_input_grad)
+        mk = _mark_begin(('fwd', len(hp['convs']), int(tokens.shape[0])))
         logits, (Bn, h, w), sv = head_forward(tokens, hp, store, training=hp['training'], save=need_grad)
         s = hp['up_scale']
         H, W = h * s, w * s
@@ -901,6 +923,7 @@ class HeadLossFn(Function):
             store.range_acquire(ctx.range)
             ctx.ncr_lo = ncr_lo
         loss = (loss_sum * k).reshape(())
+        _mark_end(mk)
         if ncr_lo is None:
             return loss
         ncr_sum = zeros_small(1, tokens.device)
@@ -913,6 +936,7 @@ class HeadLossFn(Function):
         labels, k, Bn, h, w, s = ctx.meta
         code = store.dtype
         logits = sv['logits']
+        mk = _mark_begin(('bwd', len(hp['convs']), int(Bn)))
         dlo_t = torch.empty(logits.shape, device=logits.device, dtype=torch.bfloat16) if code == BF16 else None
         # bf16 mode with the fused conv_seg gradient: nothing reads the fp32 gradient of the logits, only its T copy
         t_only = dlo_t is not None and ctx.lse is not None and _fuse_cls_grad(sv, hp) and not (ctx.ncr_lo is not None and dncr is not None)
@@ -927,6 +951,7 @@ class HeadLossFn(Function):
                       s, code, gscale_dev=ndev)
         ctx.ncr_lo = None
         dtok = head_backward(dlo, dlo_t if dlo_t is not None else dlo, sv, hp, store)
+        _mark_end(mk)
         if ctx.consumer is not None:
             dtok.record_stream(ctx.consumer)          # allocated on the head's stream, read by the backbone's
         ctx.sv = None
