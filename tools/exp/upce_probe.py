@@ -35,5 +35,7 @@ for hw, s in ((256, 2), (128, 4)):
     t = min(timeit(lambda: K.upce_bwd(lo, lab, 1.0, dlo, dlot, B, hw, hw, 21, 32, s, 1, lse=lse)) for _ in range(3))
     t2 = min(timeit(lambda: K.upce_bwd(lo, lab, 1.0, None, dlot, B, hw, hw, 21, 32, s, 1, lse=lse)) for _ in range(3))
     print(f"   T copy only: {t2:7.1f} us")
+    tf = min(timeit(lambda: K.upce_fwd(lo, lab, ls, B, hw, hw, 21, 32, s, lse_out=lse)) for _ in range(3))
+    print(f"   upce_fwd: {tf:7.1f} us")
     byt = lo.numel() * 4 + lab.numel() + lse.numel() * 4 + dlo.numel() * 6
     print(f'upce_bwd s={s} {hw}^2 x {B}: {t:7.1f} us  ({byt / t / 1e6:.2f} TB/s of algorithmic bytes)', flush=True)
