@@ -623,7 +623,7 @@ struct ClsGrad {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void cls_bn_bwd_stats_kernel(const T* __restrict__ dlo, int ld, const T* __restrict__ W,
+__global__ __launch_bounds__(256, 2) void cls_bn_bwd_stats_kernel(const T* __restrict__ dlo, int ld, const T* __restrict__ W,
                                                                const T* __restrict__ y, const float* __restrict__ scale,
                                                                const float* __restrict__ shift, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, float* __restrict__ sums,

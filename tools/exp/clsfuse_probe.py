@@ -39,6 +39,9 @@ for (B, hw) in ((8, 256), (8, 128)):
     t_s = timeit(lambda: K.bn_relu_up_bwd(dfeat, y, scale, shift, mean, rstd, None, sums, B, hw, hw, C, 1, 1))
     t_a = timeit(lambda: K.bn_bwd_apply(dfeat, y, mean, rstd, gamma, sums, npix, dy, npix, C, 1, relu_scale=scale, relu_shift=shift))
     f_s = timeit(lambda: K.cls_bn_bwd_stats(dlo, LD, w, y, scale, shift, mean, rstd, sums, npix, C, ncls, 1))
+    dwg = torch.zeros(ncls, C, device='cuda')
+    f_sw = timeit(lambda: K.cls_bn_bwd_stats(dlo, LD, w, y, scale, shift, mean, rstd, sums, npix, C, ncls, 1, seg_w_grad=dwg))
+    print(f'  stats with the conv_seg weight gradient: {f_sw:.1f} us (without: {f_s:.1f})', flush=True)
     f_a = timeit(lambda: K.cls_bn_bwd_apply(dlo, LD, w, y, scale, shift, mean, rstd, gamma, sums, npix, dy, npix, C, ncls, 1))
     bias = torch.zeros(ncls, device='cuda'); logits = torch.zeros(npix, LD, device='cuda'); feat = torch.empty(npix, C, device='cuda', dtype=T)
     t_r = timeit(lambda: K.bn_relu_up_fwd(y, scale, shift, feat, B, hw, hw, C, 1, 1))
