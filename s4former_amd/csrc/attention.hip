@@ -72,7 +72,31 @@ struct AttnArgs {
   const void* dctx; float* delta; void* dqkv;
   const float* bias_u; const float* row_flag; float bias_w;
   int B, N, H;
+  int nblk;                      // blocks per (image, head); the grid is 1-D: nblk * H * B blocks
 };
+
+// Block -> (block of the head, head, image).  The hardware deals consecutive workgroup ids round-robin to the eight XCDs (each
+// with its own 4 MiB L2); with a (blocks, H, B) grid the blocks of ONE (image, head) - which all stream that head's K and V -
+// landed on eight different XCDs and K / V were fetched once per XCD: 430 - 490 MB per launch against ~110 MB of operands
+// (profiles/r03_hbm_traffic_by_kernel.txt), 3.6 - 4.9 TB/s out of L2 for kernels that are meant to be issue-bound.  The 1-D grid
+// is cut into eight contiguous ranges of (head, block) pairs, one per XCD, as in the GEMM kernels: the blocks of a head are
+// dispatched back to back on ONE XCD and share its L2.
+struct AttnBlock { int x, h, b; };
+__device__ __forceinline__ AttnBlock attn_block(const AttnArgs& a) {
+  const int total = a.nblk * a.H * a.B;
+  int L = blockIdx.x;
+  {
+    const int xcd = L & 7, q8 = total >> 3, r8 = total & 7;
+    const int basei = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    L = basei + (L >> 3);
+  }
+  AttnBlock r;
+  r.x = L % a.nblk;
+  const int hb = L / a.nblk;
+  r.h = hb % a.H;
+  r.b = hb / a.H;
+  return r;
+}
 
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
@@ -143,13 +167,14 @@ __global__ __launch_bounds__(64 * NW, (QT == 4) ? 2 : ((NW == 8 && sizeof(T) == 
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
   const int N = a.N, H = a.H;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlock blk = attn_block(a);
+  const int b = blk.b, h = blk.h;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
   const long ld = 3L * H * 64;
   const T* qb = reinterpret_cast<const T*>(a.qkv) + (long)b * N * ld + h * 64;
   const T* kb = qb + H * 64;
   const T* vb = qb + 2 * H * 64;
-  const int q0 = blockIdx.x * (16 * QT) * NW + wave * (16 * QT);
+  const int q0 = blk.x * (16 * QT) * NW + wave * (16 * QT);
 
   Frag<T> fq[QT][2];
   float flagq[QT];
@@ -370,7 +395,8 @@ __global__ __launch_bounds__(64 * NW, 3) void attn_fwd2_kernel(const AttnArgs a)
   constexpr int BUF = 2 * C::TILE_BYTES + 64 * 4;
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
   const int N = a.N, H = a.H;
-  const int b = blockIdx.z, h = blockIdx.y, qblk = blockIdx.x;
+  const AttnBlock blk = attn_block(a);
+  const int b = blk.b, h = blk.h, qblk = blk.x;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
   const long ld = 3L * H * 64;
   const T* qb = reinterpret_cast<const T*>(a.qkv) + (long)b * N * ld + h * 64;
@@ -574,14 +600,15 @@ __global__ __launch_bounds__(64 * NW, (sizeof(T) == 2 && NW == 4) ? ATTN_DQ_MINB
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
   const int N = a.N, H = a.H;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlock blk = attn_block(a);
+  const int b = blk.b, h = blk.h;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
   const long ld = 3L * H * 64, ldc = H * 64;
   const T* qb = reinterpret_cast<const T*>(a.qkv) + (long)b * N * ld + h * 64;
   const T* kb = qb + H * 64;
   const T* vb = qb + 2 * H * 64;
   const T* dob = reinterpret_cast<const T*>(a.dctx) + (long)b * N * ldc + h * 64;
-  const int q0 = blockIdx.x * 32 * NW + wave * 32;
+  const int q0 = blk.x * 32 * NW + wave * 32;
 
   // delta = rowsum(dO * O) of this wave's queries is computed here (each (b, h, query) belongs to exactly one wave of
   // this grid) and stored for the dK/dV kernel that follows on the stream: no separate delta pass over ctx / dctx
@@ -735,14 +762,15 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
   const int N = a.N, H = a.H;
-  const int b = blockIdx.z, h = blockIdx.y;
+  const AttnBlock blk = attn_block(a);
+  const int b = blk.b, h = blk.h;
   const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, g = l >> 4, li = l & 15;
   const long ld = 3L * H * 64, ldc = H * 64;
   const T* qb = reinterpret_cast<const T*>(a.qkv) + (long)b * N * ld + h * 64;
   const T* kb = qb + H * 64;
   const T* vb = qb + 2 * H * 64;
   const T* dob = reinterpret_cast<const T*>(a.dctx) + (long)b * N * ldc + h * 64;
-  const int key0 = blockIdx.x * 32 * NW + wave * 32;
+  const int key0 = blk.x * 32 * NW + wave * 32;
 
   Frag<T> fk[2][2], fv[2][2];
   float uk[2];
@@ -888,15 +916,17 @@ __global__ __launch_bounds__(64 * NW) void attn_dkv_kernel(const AttnArgs a) {
 }
 
 template <typename T, int NW, int QT = 2>
-int fwd_launch(const AttnArgs& a, hipStream_t st) {
-  dim3 grid(ceil_div(a.N, 16 * QT * NW), a.H, a.B);
+int fwd_launch(AttnArgs a, hipStream_t st) {
+  a.nblk = ceil_div(a.N, 16 * QT * NW);
+  dim3 grid(a.nblk * a.H * a.B);
   if (a.bias_u) hipLaunchKernelGGL((attn_fwd_kernel<T, NW, true, QT>), grid, dim3(64 * NW), 0, st, a);
   else hipLaunchKernelGGL((attn_fwd_kernel<T, NW, false, QT>), grid, dim3(64 * NW), 0, st, a);
   return 0;
 }
 template <typename T, int NW>
-int bwd_launch(const AttnArgs& a, hipStream_t st) {
-  dim3 grid(ceil_div(a.N, 32 * NW), a.H, a.B);
+int bwd_launch(AttnArgs a, hipStream_t st) {
+  a.nblk = ceil_div(a.N, 32 * NW);
+  dim3 grid(a.nblk * a.H * a.B);
   if (a.bias_u) {
     hipLaunchKernelGGL((attn_dq_kernel<T, NW, true>), grid, dim3(64 * NW), 0, st, a);
     hipLaunchKernelGGL((attn_dkv_kernel<T, NW, true>), grid, dim3(64 * NW), 0, st, a);
@@ -935,7 +965,8 @@ S4F_API int s4f_attention_fwd(const void* qkv, void* ctx, float* lse, const floa
   if (dtype == S4F_BF16) {
     static const bool diet = [] { const char* e = getenv("S4F_ATTN_FWD2"); return !e || atoi(e) != 0; }();
     if (diet) {
-      dim3 grid(ceil_div(a.N, 128), a.H, a.B);
+      a.nblk = ceil_div(a.N, 128);
+      dim3 grid(a.nblk * a.H * a.B);
       if (a.bias_u) hipLaunchKernelGGL((attn_fwd2_kernel<4, true>), grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL((attn_fwd2_kernel<4, false>), grid, dim3(256), 0, st, a);
     } else if (nw == 2) fwd_launch<bf16_t, 2>(a, st); else fwd_launch<bf16_t, 4>(a, st);

@@ -34,7 +34,47 @@ def per_kernel(path, counter):
     return agg['gemm']
 
 
+def by_kernel(path, counter):
+    """{(kernel, blocks): [launches, KB]} over the last complete step, every kernel (not only the GEMM family)"""
+    rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    ema = [i for i, r in enumerate(rows) if 'ema_kernel' in r['Kernel_Name']]
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows[ema[-2]:ema[-1]]:
+        name = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '')
+        name = name.split('(')[0][:44]
+        try:
+            blocks = int(r['Grid_Size']) // max(1, int(r['Workgroup_Size']))
+        except (KeyError, ValueError):
+            blocks = 0
+        k = (name, blocks)
+        agg[k][0] += 1
+        agg[k][1] += float(r['Counter_Value'])
+    return agg
+
+
+def table(fetch_csv, write_csv, out_txt):
+    f, w = by_kernel(fetch_csv, 'FETCH_SIZE'), by_kernel(write_csv, 'WRITE_SIZE')
+    rows = []
+    for k in sorted(set(f) | set(w)):
+        n = f.get(k, w.get(k))[0]
+        fb = 2.0 * f.get(k, [0, 0.0])[1] * 1024 / max(n, 1) / 1e6
+        wb = w.get(k, [0, 0.0])[1] * 1024 / max(n, 1) / 1e6
+        rows.append((n * (fb + wb), k[0], k[1], n, fb, wb))
+    rows.sort(reverse=True)
+    tot = sum(r[0] for r in rows)
+    with open(out_txt, 'w') as fh:
+        fh.write('HBM-side traffic of one step by kernel and grid (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH doubled for\n'
+                 'gfx950, MB per launch; FETCH counts requests that left L2 - reads served by the Infinity Cache included).  Step total '
+                 f'{tot / 1e3:.1f} GB.\n\n')
+        fh.write(f'{"kernel":46s} {"blocks":>8s} {"launches":>8s} {"fetch MB":>10s} {"write MB":>10s} {"step GB":>8s}\n')
+        for t, name, blocks, n, fb, wb in rows[:60]:
+            fh.write(f'{name:46s} {blocks:8d} {n:8d} {fb:10.1f} {wb:10.1f} {t / 1e3:8.2f}\n')
+
+
 def main():
+    if len(sys.argv) > 4:
+        table(sys.argv[1], sys.argv[2], sys.argv[4])
     fetch_n, fetch_kb = per_kernel(sys.argv[1], 'FETCH_SIZE')
     write_n, write_kb = per_kernel(sys.argv[2], 'WRITE_SIZE')
     assert fetch_n == write_n, (fetch_n, write_n)

@@ -23,7 +23,7 @@ echo "== HBM traffic of the GEMM family (two pmc passes) $(date +%T)"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$out/pmc_fetch" -- python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-kernel-profile > "$out/pmc_fetch.log" 2>&1 || { tail -5 "$out/pmc_fetch.log"; exit 1; }
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$out/pmc_write" -- python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-kernel-profile > "$out/pmc_write.log" 2>&1 || { tail -5 "$out/pmc_write.log"; exit 1; }
 ff=$(find "$out/pmc_fetch" -name '*counter_collection.csv' | head -1); fw=$(find "$out/pmc_write" -name '*counter_collection.csv' | head -1)
-python3 $R/tools/pmc_traffic.py "$ff" "$fw" "$out/${tag}_gemm_hbm_traffic.json" > /dev/null
+python3 $R/tools/pmc_traffic.py "$ff" "$fw" "$out/${tag}_gemm_hbm_traffic.json" "$out/${tag}_hbm_traffic_by_kernel.txt" > /dev/null
 echo "== attention $(date +%T)"
 python3 $R/tools/attn_probe.py > "$out/${tag}_attention_probe.txt" 2>&1
 $R/tools/exp/pmc_attn.sh "$out/pmc_attn_fwd" attn > "$out/${tag}_pmc_attention_fwd.txt" 2>&1
