@@ -307,13 +307,20 @@ __device__ __forceinline__ void g6_body(const GemmArgs& args, const int tm, cons
   });
 }
 
-__device__ __forceinline__ void tile_of(const GemmArgs& args, int L, int& tm, int& tn) {
-  // XCD-aware bijective remap + grouped tile order (as gemm2.hip)
-  const int nt = args.tiles_m * args.tiles_n;
-  const int xcd = L & 7, q8 = nt >> 3, r8 = nt & 7;
+// Work order.  A block is one (k-range, output tile) pair.  The hardware deals consecutive workgroup ids round-robin to the
+// eight XCDs, each with its own 4 MiB L2; the operands of a weight gradient are k-major PANELS ([rows of the k-range] x 256
+// columns, 4 MiB and more) that every tile of the same k-range and tile row / column streams through L2 at the same pace.
+// With a (tiles, 1, splits) grid those tiles sat on eight different XCDs and every panel was fetched up to nine times: the
+// conv weight gradients pulled 1.9 GB per launch (4.8 TB/s: HBM-bound at 700 TFLOP/s), the layer's grouped weight gradient
+// 1.18 GB against 0.40 GB of operands (profiles/r03_hbm_traffic_by_kernel.txt).  Round 3: ONE linear work index, k-range-major
+// (problem, k-range, tile), cut into eight contiguous ranges, one per XCD - the tiles of a k-range run side by side on one XCD.
+__device__ __forceinline__ int xcd_range(int L, int total) {
+  const int xcd = L & 7, q8 = total >> 3, r8 = total & 7;
   const int basei = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-  L = basei + (L >> 3);
-  constexpr int GM = 8;
+  return basei + (L >> 3);
+}
+__device__ __forceinline__ void tile_of(const GemmArgs& args, int L, int& tm, int& tn) {
+  constexpr int GM = 8;                                // grouped tile order (as gemm2.hip)
   const int per_group = GM * args.tiles_n;
   const int grp = L / per_group, r = L - grp * per_group;
   const int rows_here = min(GM, args.tiles_m - grp * GM);
@@ -324,26 +331,36 @@ __device__ __forceinline__ void tile_of(const GemmArgs& args, int L, int& tm, in
 template <int BMODE>
 __global__ __launch_bounds__(512) void gemm6_kernel(const GemmArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nt = args.tiles_m * args.tiles_n;
+  const int W = xcd_range(blockIdx.x, nt * args.sk);
+  const int z = W / nt;
   int tm, tn;
-  tile_of(args, blockIdx.x, tm, tn);
-  g6_body<BMODE>(args, tm, tn, blockIdx.z, smem);
+  tile_of(args, W - z * nt, tm, tn);
+  g6_body<BMODE>(args, tm, tn, z, smem);
 }
 
-__global__ __launch_bounds__(512) void gemm6_grouped_kernel(const GroupArgs g) {
+struct GroupArgs6 {
+  GemmArgs p[kMaxGroup];
+  int work_end[kMaxGroup];                             // running sum of tiles x k-ranges over the problems
+};
+
+__global__ __launch_bounds__(512) void gemm6_grouped_kernel(const GroupArgs6 g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int bx = blockIdx.x;
+  const int W = xcd_range(blockIdx.x, g.work_end[kMaxGroup - 1]);
   int which = 0;
 #pragma unroll
-  for (int i = 0; i < kMaxGroup - 1; ++i) which += bx >= g.tile_end[i] ? 1 : 0;
+  for (int i = 0; i < kMaxGroup - 1; ++i) which += W >= g.work_end[i] ? 1 : 0;
   GemmArgs args = g.p[0];
   int start = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
-    if (which == i) { args = g.p[i]; start = g.tile_end[i - 1]; }
-  if ((int)blockIdx.z * args.nk_per_split >= args.nk) return;      // this problem has fewer k-splits than the grid
+    if (which == i) { args = g.p[i]; start = g.work_end[i - 1]; }
+  const int nt = args.tiles_m * args.tiles_n;
+  const int local = W - start;
+  const int z = local / nt;
   int tm, tn;
-  tile_of(args, bx - start, tm, tn);
-  g6_body<S4F_OP_K>(args, tm, tn, blockIdx.z, smem);
+  tile_of(args, local - z * nt, tm, tn);
+  g6_body<S4F_OP_K>(args, tm, tn, z, smem);
 }
 
 static bool fill_args(GemmArgs& a, const s4f_gemm_desc& d) {
@@ -374,21 +391,18 @@ int launch6(const s4f_gemm_desc& d, hipStream_t st) {
     hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, 1, a.sk), dim3(512), shm, st, a);
+  hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n * a.sk), dim3(512), shm, st, a);
   return 0;
 }
 
 int launch6_grouped(const s4f_gemm_desc* ds, int count, hipStream_t st) {
-  GroupArgs g;
-  int total = 0, zmax = 1;
+  GroupArgs6 g;
+  int total = 0;
   for (int i = 0; i < kMaxGroup; ++i) {
     GemmArgs& a = g.p[i];
     if (!fill_args(a, ds[i < count ? i : count - 1])) return -100;
-    if (i < count) {
-      total += a.tiles_m * a.tiles_n;
-      if (a.sk > zmax) zmax = a.sk;
-    }
-    g.tile_end[i] = total;
+    if (i < count) total += a.tiles_m * a.tiles_n * a.sk;
+    g.work_end[i] = total;
   }
   const size_t shm = 2 * (size_t)G6_BUF + 4096;
   static bool attr_set = false;
@@ -396,7 +410,7 @@ int launch6_grouped(const s4f_gemm_desc* ds, int count, hipStream_t st) {
     hipFuncSetAttribute((const void*)gemm6_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm6_grouped_kernel, dim3(total, 1, zmax), dim3(512), shm, st, g);
+  hipLaunchKernelGGL(gemm6_grouped_kernel, dim3(total), dim3(512), shm, st, g);
   return 0;
 }
 
