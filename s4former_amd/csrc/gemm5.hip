@@ -27,6 +27,10 @@
 
 namespace g5 {
 
+#ifndef S4F_CONV_TAP_ROTATION
+#define S4F_CONV_TAP_ROTATION 1
+#endif
+
 constexpr int P_AL = 0, P_AH = 1, P_BL = 0, P_BH = 1;
 constexpr int G5_A = 256 * 128, G5_B = 256 * 128;   // bytes of the A / B image of one K-tile
 constexpr int G5_TAILB = 8 * 1024;                    // tail region per buffer: one DMA per wave (2 KiB used)
@@ -54,6 +58,8 @@ struct PFeeder {
   int chunk;                    // source 16-B chunk of this lane inside the 128-B k-row (swizzle applied)
   int soff[2];                  // conv: scalar byte offset of the part's current tap is folded into voff; this is the k base
   int tpt, tleft[2];            // conv: K-tiles per tap; K-tiles until the part's next tap change
+  int rot;                      // conv, one image row per tile: taps are visited so that input row r is read in phase r % 3 (-1: off)
+  int bdelta[2];                // B of a rotated conv: byte offset of the part's physical tap relative to its logical position
   int wave;
 
   // 8-row block of slot u: A parts are rows {0-63, 128-191} / {64-127, 192-255}; B parts are the low / high 32 columns
@@ -65,13 +71,27 @@ struct PFeeder {
     return 8 * (e >> 2) + (e & 3) + 4 * part;
   }
 
+  // Tap order of a rotated conv (round 3).  A 256-pixel tile is one image row y and reads input rows y - 1, y, y + 1, a third
+  // of its K loop each; the 32 tiles an XCD runs side by side (32 consecutive rows) touch every input row three times, a third
+  // of a tile's duration apart, with 4.4 MB of other rows streaming through the 4 MiB L2 in between: 1.37 GB fetched per
+  // launch for 0.27 GB of input (profiles/r03_hbm_traffic_by_kernel.txt).  Visiting the taps so that input row r is read in
+  // phase r % 3 by EVERY tile makes the three readers of a row read it at the same time.  Logical step s (0 .. 8) -> tap.
+  __device__ __forceinline__ int phys_tap(int s_) const {
+    if (rot < 0) return s_;
+    const int j = s_ / 3, tx = s_ - 3 * j;
+    int t = 1 + csign * (j - rot);
+    t = ((t % 3) + 3) % 3;
+    return 3 * t + tx;
+  }
+
   template <int PART>
   __device__ __forceinline__ void seek(int kt) {
     if constexpr (MODE == S4F_OP_ROW_CONV) {
       const int k0 = kt * BK;
-      const int tap = k0 / cC;
+      const int step = k0 / cC;
+      const int tap = phys_tap(step);
       const int ty = tap / 3, tx = tap - 3 * ty;
-      soff[PART] = (tap * cC) * 2;                   // k bytes already consumed by earlier taps
+      soff[PART] = (step * cC) * 2;                  // k bytes already consumed by earlier taps
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int u = 2 * PART + i;
@@ -79,10 +99,17 @@ struct PFeeder {
         const bool ok = pb[u] >= 0 && yy >= 0 && yy < cH && xx >= 0 && xx < cW;
         voff[u] = ok ? (int)(((((long)pb[u] * cH + yy) * cW + xx) * ld + chunk * 8) * 2) : G5_OOB;
       }
+    } else if constexpr (!IS_A) {
+      if (rot >= 0) {                                // the weights of the tap the rotated A side reads in this step
+        const int step = (kt * BK) / cC;
+        bdelta[PART] = (phys_tap(step) - step) * cC * 2;
+      }
     }
   }
 
-  __device__ __forceinline__ void init(const s4f_gemm_desc& d, int blk0, int kt0, int kt_end_) {
+  __device__ __forceinline__ void init(const s4f_gemm_desc& d, int blk0, int kt0, int kt_end_, int rot_ = -1) {
+    rot = rot_;
+    bdelta[0] = bdelta[1] = 0;
     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: LDS-DMA bases (M0) without per-issue readfirstlane
     const int lane = threadIdx.x & 63;
     const void* basep = IS_A ? d.A : d.B;
@@ -109,7 +136,7 @@ struct PFeeder {
     }
     seek<0>(kt0);
     seek<1>(kt0);
-    if constexpr (MODE == S4F_OP_ROW_CONV) {
+    if (MODE == S4F_OP_ROW_CONV || (!IS_A && rot >= 0)) {
       tpt = cC / BK;
       // issue(kt) is called once per K-tile and part in ascending order starting at kt0: the first call must not re-seek
       tleft[0] = tleft[1] = tpt - (kt0 % tpt) + 1;
@@ -119,7 +146,7 @@ struct PFeeder {
   // two DMA instructions: part PART of K-tile kt into the image at img
   template <int PART>
   __device__ __forceinline__ void issue(int kt, char* img) {
-    if constexpr (MODE == S4F_OP_ROW_CONV) {
+    if (MODE == S4F_OP_ROW_CONV || (!IS_A && rot >= 0)) {
       // wave-uniform tap change every cC / 64 K-tiles: a countdown per part instead of an integer modulo per issue
       if (--tleft[PART] == 0) {
         tleft[PART] = tpt;
@@ -127,7 +154,7 @@ struct PFeeder {
       }
     }
     const bool live = kt < kt_end;                   // scalar
-    const int so = kt * (BK * 2) - (MODE == S4F_OP_ROW_CONV ? soff[PART] : 0);
+    const int so = kt * (BK * 2) - (MODE == S4F_OP_ROW_CONV ? soff[PART] : 0) + ((!IS_A && MODE == S4F_OP_ROW) ? bdelta[PART] : 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int u = 2 * PART + i;
@@ -150,8 +177,13 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
 
   PFeeder<AMODE, true> fa;
   PFeeder<S4F_OP_ROW, false> fb;
-  fa.init(d, m0, kt_beg, kt_end);
-  fb.init(d, n0, kt_beg, kt_end);
+  int rot = -1;
+  if constexpr (AMODE == S4F_OP_ROW_CONV) {
+    // the tile is R = 256 / cW whole image rows starting at row y (R = 1 at the 256 x 256 stage): phase = (y + dy) % 3
+    if (BM % d.cW == 0 && (d.cH * d.cW) % BM == 0 && d.cH >= 3 && S4F_CONV_TAP_ROTATION) rot = ((m0 / d.cW) % d.cH) % 3;
+  }
+  fa.init(d, m0, kt_beg, kt_end, rot);
+  fb.init(d, n0, kt_beg, kt_end, rot);
 
   // folded tail: every wave issues ONE extra DMA with the AL part (waves 0 / 1 fetch the 16 tail rows, the others an
   // out-of-range offset = zeros into a dummy slot) so that the vmcnt bookkeeping is the same in all waves
