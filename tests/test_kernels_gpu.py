@@ -225,7 +225,7 @@ def test_layernorm(K, code, skip):
 
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize('code', DTYPES)
-@pytest.mark.parametrize('B,N,H,bias', [(2, 197, 12, 0), (1, 130, 3, 1), (2, 65, 2, 2), (1, 1025, 2, 0)])
+@pytest.mark.parametrize('B,N,H,bias', [(2, 197, 12, 0), (1, 130, 3, 1), (2, 65, 2, 2), (1, 1025, 2, 0), (3, 300, 5, 1)])   # (block counts 48, 6, 4, 18, 45: the 1-D grid's XCD ranges with and without remainders)
 def test_attention(K, code, B, N, H, bias):
     C = H * 64
     qkv = q(rnd(B, N, 3 * C, seed=1), code)
