@@ -168,6 +168,17 @@ int s4f_attention_fwd(const void* qkv, void* ctx, float* lse, const float* bias_
 int s4f_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta,
                       void* dqkv, const float* bias_u, const float* row_flag, float bias_w, int B, int N, int H,
                       int dtype, s4f_stream stream);
+/* Round 4: the same backward (bf16 only) as ONE sweep over the scores - five MFMA products per score tile instead of the seven
+ * of the two-kernel form above, which recomputes S and dP for dQ and again for dK / dV (guide, Appendix B "Attention
+ * backward": a workgroup owns 256 keys of one (image, head) with dK / dV in accumulators, S and dP with the key on the lane,
+ * -lse and -delta as the start accumulators, dS through LDS once for dQ).  dQ is summed over the key blocks of a head from
+ * fp32 slabs written with plain stores (bitwise reproducible); token 0 (the odd cls key of N = 1 + 16 k) is a matrix-vector
+ * side path of the pre / slab passes.  ws: workspace of at least s4f_attention_bwd_ws_bytes(B, N, H) bytes, 256-byte aligned,
+ * contents undefined on entry and exit.  Other arguments as s4f_attention_bwd. */
+int64_t s4f_attention_bwd_ws_bytes(int B, int N, int H);
+int s4f_attention_bwd_fused(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta,
+                            void* dqkv, const float* bias_u, const float* row_flag, float bias_w, int B, int N,
+                            int H, void* ws, int64_t ws_bytes, s4f_stream stream);
 
 /* ------------------------------------------------------------------------------------------- encoder layer (round 3)
  * TransformerEncoderLayer.forward (vit.py:113-127: LN -> MultiheadAttention -> +x; LN -> FFN(GELU) -> +x) and its backward as ONE

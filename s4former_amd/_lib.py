@@ -78,6 +78,8 @@ _SIGS = {
     's4f_attention_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
                           c_void_p],
     's4f_attention_bwd': [c_void_p] * 8 + [c_float, c_int, c_int, c_int, c_int, c_void_p],
+    's4f_attention_bwd_fused': [c_void_p] * 8 + [c_float, c_int, c_int, c_int, c_void_p, c_int64, c_void_p],
+    's4f_attention_bwd_ws_bytes': [c_int, c_int, c_int],
     's4f_bn_stats': [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p],
     's4f_bn_finalize': [c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
@@ -113,6 +115,7 @@ _SIGS = {
     's4f_sgd_momentum': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int, c_int,
                          c_void_p],
 }
+_RESTYPES = {'s4f_attention_bwd_ws_bytes': c_int64}     # everything else returns the int status
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ['s4f_last_error', 's4f_version'])
 
 
@@ -134,7 +137,7 @@ def load():
     lib.s4f_version.restype = c_int
     for name, sig in _SIGS.items():
         fn = getattr(lib, name)
-        fn.restype = c_int
+        fn.restype = _RESTYPES.get(name, c_int)
         fn.argtypes = sig
     _lib = lib
     return lib

@@ -12,7 +12,7 @@ from ._lib import (ACT_COLSTATS, ACT_GELU, ACT_GELU_BWD, ACT_NONE, BF16, F32, OP
                    OP_ROW_CONV, S4FError, call, p, stream)
 
 __all__ = ['gemm', 'wgrad_grouped', 'transpose_many', 'cast', 'cast_back', 'im2col_patch16', 'cls_pos', 'tokens_bwd', 'colsum', 'layernorm_fwd',
-           'layernorm_bwd', 'add_f32', 'attention_fwd', 'attention_bwd', 'bn_stats', 'bn_finalize',
+           'layernorm_bwd', 'add_f32', 'attention_fwd', 'attention_bwd', 'attention_bwd_fused', 'attention_bwd_ws_bytes', 'bn_stats', 'bn_finalize',
            'bn_relu_up_fwd', 'bn_relu_up_bwd', 'bn_bwd_apply', 'bn_param_grads', 'upce_fwd', 'upce_bwd',
            'up_pseudo_label', 'up_logits_nchw', 'ce_fwd', 'ce_bwd', 'ema', 'sgd_momentum', 'ncr_fwd', 'ncr_bwd', 'mix_images',
            'cutmix_labels', 'gather_rows', 'resize_bilinear', 'softmax_argmax', 'confusion_counts']
@@ -437,6 +437,26 @@ def attention_bwd(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, dtype, bias_u=None,
     _need(row_flag, B * N if row_flag is not None else 0, 'attn_bwd row_flag')
     call('s4f_attention_bwd', p(qkv), p(ctx), p(dctx), p(lse), p(delta), p(dqkv), p(bias_u), p(row_flag), bias_w, B, N,
          H, dtype, stream())
+
+
+def attention_bwd_ws_bytes(B, N, H):
+    return int(L.load().s4f_attention_bwd_ws_bytes(B, N, H))
+
+
+def attention_bwd_fused(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, ws, bias_u=None, row_flag=None, bias_w=0.0):
+    """bf16 only; ws: uint8 / any-dtype device tensor of at least attention_bwd_ws_bytes(B, N, H) bytes"""
+    for t, w in ((qkv, 'qkv'), (ctx, 'ctx'), (dctx, 'dctx'), (dqkv, 'dqkv')):
+        _chk_dtype(t, BF16, 'attn_bwd_fused ' + w)
+    for t in (lse, delta, bias_u, row_flag):
+        _chk_f32(t, 'attn_bwd_fused')
+    _need(qkv, B * N * 3 * H * 64, 'attn_bwd_fused qkv'); _need(dqkv, B * N * 3 * H * 64, 'attn_bwd_fused dqkv')
+    _need(ctx, B * N * H * 64, 'attn_bwd_fused ctx'); _need(dctx, B * N * H * 64, 'attn_bwd_fused dctx')
+    _need(lse, B * H * N, 'attn_bwd_fused lse'); _need(delta, B * H * N, 'attn_bwd_fused delta')
+    _need(bias_u, B * N if bias_u is not None else 0, 'attn_bwd_fused bias_u')
+    _need(row_flag, B * N if row_flag is not None else 0, 'attn_bwd_fused row_flag')
+    nbytes = ws.numel() * ws.element_size()
+    call('s4f_attention_bwd_fused', p(qkv), p(ctx), p(dctx), p(lse), p(delta), p(dqkv), p(bias_u), p(row_flag), bias_w, B, N,
+         H, p(ws), nbytes, stream())
 
 
 def bn_stats(x, rows, C, sums, dtype):

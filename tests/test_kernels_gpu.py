@@ -257,6 +257,55 @@ def test_attention(K, code, B, N, H, bias):
               tol=2e-4 if code == 0 else 4e-2)
 
 
+@pytest.mark.parametrize('B,N,H,bias', [(2, 197, 12, 0), (1, 130, 3, 1), (2, 65, 2, 2), (1, 1025, 2, 0), (3, 300, 5, 1), (1, 2305, 1, 2),
+                                        (2, 257, 2, 2), (1, 258, 1, 1), (2, 1, 2, 0), (1, 2, 1, 1), (1, 513, 3, 2)])
+def test_attention_bwd_fused(K, B, N, H, bias):
+    """round 4: the one-sweep backward (five MFMA products per score tile, dQ through fp32 slabs, the cls key as a side path)
+    against the oracle's autograd AND against the two-kernel form it replaces; ragged key blocks (N - 1 not a multiple of 256),
+    exactly one / two key blocks, N = 1 (no patch key at all), query slices with one row"""
+    code = 1
+    C = H * 64
+    qkv = q(rnd(B, N, 3 * C, seed=1), code)
+    dctx = q(rnd(B, N, C, seed=2), code)
+    bias_full = bias_u = flag = None
+    w = 0.0
+    if bias and N > 1:
+        u = torch.rand(B, N - 1, generator=torch.Generator().manual_seed(3))
+        w = 5.0
+        bias_full = O.pasa_bias(u, w, adaptive=(bias == 2))
+        bias_u, flag = O.pasa_rank1(u, adaptive=(bias == 2))
+    else:
+        bias = 0
+    qr = qkv.clone().requires_grad_(True)
+    ctx_ref, lse_ref = O.attention_core(qr, H, bias_full)
+    ctx_ref.backward(dctx)
+    ctx = torch.empty(B, N, C, device='cuda', dtype=tdt(code))
+    lse = torch.empty(B, H, N, device='cuda')
+    qd = dev(qkv, code)
+    bu = dev(bias_u) if bias else None
+    fl = dev(flag) if bias == 2 else None
+    K.attention_fwd(qd, ctx, lse, B, N, H, code, bias_u=bu, row_flag=fl, bias_w=w)
+    delta = torch.full((B, H, N), float('nan'), device='cuda')
+    dqkv = torch.full((B, N, 3 * C), float('nan'), device='cuda', dtype=tdt(code))
+    nb = K.attention_bwd_ws_bytes(B, N, H)
+    ws = torch.full((nb // 4 + 64,), float('nan'), device='cuda')            # poisoned: nothing may be read before it is written
+    K.attention_bwd_fused(qd, ctx, dev(dctx, code), lse, delta, dqkv, B, N, H, ws, bias_u=bu, row_flag=fl, bias_w=w)
+    for i, nm in enumerate(('dq', 'dk', 'dv')):
+        check(dqkv[..., i * C:(i + 1) * C], qr.grad[..., i * C:(i + 1) * C], code, f'fused attention backward {nm}', tol=4e-2)
+    # the two-kernel form on the same inputs: both are bf16 renderings of the same sums
+    delta2 = torch.empty(B, H, N, device='cuda')
+    dqkv2 = torch.full((B, N, 3 * C), float('nan'), device='cuda', dtype=tdt(code))
+    K.attention_bwd(qd, ctx, dev(dctx, code), lse, delta2, dqkv2, B, N, H, code, bias_u=bu, row_flag=fl, bias_w=w)
+    check(delta, delta2.cpu(), 0, 'fused attention backward delta', tol=1e-5)
+    check(dqkv, dqkv2.float().cpu(), code, 'fused vs two-kernel attention backward', tol=2e-2)
+    # bitwise reproducible (no atomics anywhere on the path)
+    dq3 = torch.full((B, N, 3 * C), float('nan'), device='cuda', dtype=tdt(code))
+    K.attention_bwd_fused(qd, ctx, dev(dctx, code), lse, delta, dq3, B, N, H, ws, bias_u=bu, row_flag=fl, bias_w=w)
+    assert torch.equal(dq3, dqkv), 'the fused attention backward must be bitwise reproducible'
+    with pytest.raises(Exception):
+        K.attention_bwd_fused(qd, ctx, dev(dctx, code), lse, delta, dq3, B, N, H, ws[:max(1, nb // 8)], bias_u=bu, row_flag=fl, bias_w=w)
+
+
 # ------------------------------------------------------------------------------------------------ conv3x3
 def to_nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()

@@ -35,5 +35,10 @@ for (Bn, bias, N) in ((16, True, 1025), (16, False, 1025), (8, False, 1025), (8,
     fl = (torch.rand(Bn, N, device='cuda') > 0.5).float() if bias else None
     f = timeit(lambda: K.attention_fwd(qkv, ctx, lse, Bn, N, H, 1, bias_u=bu, row_flag=fl, bias_w=5.0))
     b = timeit(lambda: K.attention_bwd(qkv, ctx, dctx, lse, delta, dqkv, Bn, N, H, 1, bias_u=bu, row_flag=fl, bias_w=5.0))
+    ws = torch.empty(K.attention_bwd_ws_bytes(Bn, N, H), device='cuda', dtype=torch.uint8)
+    dq2 = torch.empty_like(qkv)
+    b1 = timeit(lambda: K.attention_bwd_fused(qkv, ctx, dctx, lse, delta, dq2, Bn, N, H, ws, bias_u=bu, row_flag=fl, bias_w=5.0))
     gf = 4.0 * Bn * H * N * N * 64 / 1e9
-    print(f'B={Bn} N={N} bias={bias}: fwd {f:7.1f} us ({gf / f * 1e3:6.0f} TF/s)   bwd {b:7.1f} us ({2.5 * gf / b * 1e3:6.0f} TF/s algorithmic)', flush=True)
+    err = ((dq2.float() - dqkv.float()).abs().max() / dqkv.float().abs().max()).item()
+    print(f'B={Bn} N={N} bias={bias}: fwd {f:7.1f} us ({gf / f * 1e3:6.0f} TF/s)   bwd two-kernel {b:7.1f} us ({2.5 * gf / b * 1e3:6.0f} TF/s algorithmic)'
+          f'   bwd one-sweep {b1:7.1f} us ({2.5 * gf / b1 * 1e3:6.0f} TF/s)  [max diff {err:.2e}]', flush=True)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counters of the attention kernels (rocprofv3 --pmc in its own run, kernel-trace only): tools/exp/pmc_attn.sh <out dir> [attn|attnb]
+# SQ counters of the attention kernels (rocprofv3 --pmc in its own run, kernel-trace only): tools/exp/pmc_attn.sh <out dir> [attn|attnb|attnf]
 out=$1; what=${2:-attn}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p "$out"
@@ -12,7 +12,7 @@ for p in ('p1', 'p2'):
     for f in glob.glob(f'{out}/{p}/**/*counter_collection.csv', recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            if 'attn' in r['Kernel_Name']:
+            if 'attn' in r['Kernel_Name'] or 'fb::' in r['Kernel_Name']:
                 agg[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, d in agg.items():
             print(p, k)

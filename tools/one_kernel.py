@@ -30,7 +30,7 @@ elif what.startswith('convw'):   # convw:hw:cin:cout:splitk   conv weight gradie
         K.gemm(dy, x, cout, 9 * cin, Mp, cout, cin, 1, a_mode=K.OP_K, b_mode=K.OP_K_CONV, out_f32=dw, ldo_f32=9 * cin, atomic=True,
                splitk=sk, conv=(B, hw, hw, cin, 1), tile_hint=hint)
     print('GFLOP', 2.0 * Mp * cout * 9 * cin / 1e9)
-elif what in ('attn', 'attnb'):
+elif what in ('attn', 'attnb', 'attnf'):
     Bn, N, H = 16, 1025, 12
     qkv = torch.randn(Bn, N, 3 * 768, device='cuda').to(T)
     ctx = torch.empty(Bn, N, 768, device='cuda', dtype=T)
@@ -39,9 +39,12 @@ elif what in ('attn', 'attnb'):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
     K.attention_fwd(qkv, ctx, lse, Bn, N, H, 1)
+    ws = torch.empty(K.attention_bwd_ws_bytes(Bn, N, H), device='cuda', dtype=torch.uint8)
     def run():
         if what == 'attn':
             K.attention_fwd(qkv, ctx, lse, Bn, N, H, 1)
+        elif what == 'attnf':
+            K.attention_bwd_fused(qkv, ctx, dctx, lse, delta, dqkv, Bn, N, H, ws)
         else:
             K.attention_bwd(qkv, ctx, dctx, lse, delta, dqkv, Bn, N, H, 1)
 elif what == 'big':      # plain NT 8192^2 x 4096: no gather, no edge
