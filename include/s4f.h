@@ -211,6 +211,8 @@ typedef struct s4f_layer_desc {
   void* dz; void* dxn2; void* g1; void* g1t; void* dctx; void* dqkv; float* delta; void* dxn; void* g0; void* g0t; float* g0cs;
   /* parameter gradients (fp32, accumulated) */
   float *d_ln1_g, *d_ln1_b, *d_ln2_g, *d_ln2_b, *d_wqkv, *d_bqkv, *d_wo, *d_bo, *d_w1, *d_b1, *d_w2, *d_b2;
+  /* round 4: workspace of the one-sweep attention backward (s4f_attention_bwd_fused; bf16 only) or NULL = the two-kernel form */
+  void* attn_ws; int64_t attn_ws_bytes;
 } s4f_layer_desc;
 
 int s4f_encoder_layer_fwd(const s4f_layer_desc* d, s4f_stream stream);

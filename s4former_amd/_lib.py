@@ -53,10 +53,11 @@ class LayerDesc(Structure):
                     'bias_u', 'row_flag',
                     'x', 'xn', 'mean1', 'rstd1', 'qkv', 'ctx', 'lse', 'x1', 'xn2', 'mean2', 'rstd2', 'gelu_d', 'a', 'x2',
                     'g2', 'g2t', 'g2cs', 'dz', 'dxn2', 'g1', 'g1t', 'dctx', 'dqkv', 'delta', 'dxn', 'g0', 'g0t', 'g0cs',
-                    'd_ln1_g', 'd_ln1_b', 'd_ln2_g', 'd_ln2_b', 'd_wqkv', 'd_bqkv', 'd_wo', 'd_bo', 'd_w1', 'd_b1', 'd_w2', 'd_b2')])
+                    'd_ln1_g', 'd_ln1_b', 'd_ln2_g', 'd_ln2_b', 'd_wqkv', 'd_bqkv', 'd_wo', 'd_bo', 'd_w1', 'd_b1', 'd_w2', 'd_b2', 'attn_ws')] +
+                [('attn_ws_bytes', c_int64)])
 
 
-assert ctypes.sizeof(LayerDesc) == 552, 'LayerDesc must mirror s4f_layer_desc (include/s4f.h, static_assert in layer.hip)'
+assert ctypes.sizeof(LayerDesc) == 568, 'LayerDesc must mirror s4f_layer_desc (include/s4f.h, static_assert in layer.hip)'
 
 
 _SIGS = {

@@ -33,7 +33,8 @@ constexpr int KB = 256;                         // keys per workgroup
 constexpr int QS = 64;                          // queries per slice
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kScale2 = 0.125f * kLog2e;      // (1/8) log2(e): scores in log2 units
-constexpr int PRE_ROWS = 64;                    // query rows per pre-pass block
+constexpr int PRE_IT = 4;                       // rows per thread of the pre-pass
+constexpr int PRE_ROWS = 64 * PRE_IT;           // query rows per pre-pass block
 
 struct Args {
   const bf16_t* qkv; const bf16_t* ctx; const bf16_t* dctx; const float* lse;
@@ -130,7 +131,7 @@ __device__ __forceinline__ bf16x8 ld8(const bf16_t* p, bool valid) {
 // ---------------------------------------------------------------------------------------------------------------- pre-pass
 // delta[b,h,q] = sum_d dO O, and the column of the cls key (token 0): p0 = exp2(q.k0~ - lse2 [+ bias]), ds0 = p0 (dO.v0 - delta)
 // (stored for the slab pass: dQ[q] += ds0 k0), partial sums of dV[0] = sum_q p0 dO[q] and dK[0] = sum_q ds0 Q[q] per block of
-// 64 queries (kv0[b][h][chunk][128], summed in fixed order by the slab pass: reproducible, no atomics, nothing to zero).
+// 256 queries (kv0[b][h][chunk][128], summed in fixed order by the slab pass: reproducible, no atomics, nothing to zero).
 template <bool HAS_BIAS>
 __global__ __launch_bounds__(256) void pre_kernel(const Args a) {
   __shared__ float red[4][128];
@@ -141,49 +142,74 @@ __global__ __launch_bounds__(256) void pre_kernel(const Args a) {
   const int hd = L % H, b = L / H;
   const int tid = threadIdx.x, row = tid >> 2, part = tid & 3, wave = tid >> 6;
   const long ld = 3L * H * 64, ldc = H * 64;
-  const int q = chunk * PRE_ROWS + row;
-  const bool v = q < N;
   const bf16_t* qb = a.qkv + (long)b * N * ld + hd * 64 + part * 16;
   const bf16_t* dob = a.dctx + (long)b * N * ldc + hd * 64 + part * 16;
   const bf16_t* ob = a.ctx + (long)b * N * ldc + hd * 64 + part * 16;
-  float s0 = 0.f, dp0 = 0.f, dl = 0.f;
-  float qf[16], dof[16];
+  float ks[16], v0f[16];                  // key 0 of this (image, head): K~ as the main kernel rounds it, V
 #pragma unroll
   for (int c2 = 0; c2 < 2; ++c2) {
-    const bf16x8 qv = ld8(qb + (long)q * ld + 8 * c2, v);
-    const bf16x8 dv = ld8(dob + (long)q * ldc + 8 * c2, v);
-    const bf16x8 ov = ld8(ob + (long)q * ldc + 8 * c2, v);
-    const bf16x8 k0 = ld8(qb + H * 64 + 8 * c2, true);            // key 0 of this (image, head)
+    const bf16x8 k0 = ld8(qb + H * 64 + 8 * c2, true);
     const bf16x8 v0 = ld8(qb + 2 * H * 64 + 8 * c2, true);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float qq = (float)qv[j], dd = (float)dv[j];
-      qf[8 * c2 + j] = qq; dof[8 * c2 + j] = dd;
-      const float ks = (float)(bf16_t)((float)k0[j] * kScale2);   // K~ as the main kernel rounds it
-      s0 = fmaf(qq, ks, s0);
-      dp0 = fmaf(dd, (float)v0[j], dp0);
-      dl = fmaf(dd, (float)ov[j], dl);
+    for (int j = 0; j < 8; ++j) { ks[8 * c2 + j] = (float)(bf16_t)((float)k0[j] * kScale2); v0f[8 * c2 + j] = (float)v0[j]; }
+  }
+  const float b0 = HAS_BIAS ? a.bias_w * kLog2e * a.bias_u[(long)b * N] : 0.f;
+  float kk[16], vv[16];                   // this lane's 16 head dims of dK[0], dV[0], summed over its rows
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { kk[i] = 0.f; vv[i] = 0.f; }
+  // four rows per thread (all 24 loads of a thread in flight together), then ONE cross-lane reduction per block
+  bf16x8 qv[PRE_IT][2], dv[PRE_IT][2], ov[PRE_IT][2];
+#pragma unroll
+  for (int it = 0; it < PRE_IT; ++it) {
+    const int q = min(chunk * PRE_ROWS + 64 * it + row, N - 1);
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      qv[it][c2] = ld8(qb + (long)q * ld + 8 * c2, true);
+      dv[it][c2] = ld8(dob + (long)q * ldc + 8 * c2, true);
+      ov[it][c2] = ld8(ob + (long)q * ldc + 8 * c2, true);
     }
   }
-  s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
-  dp0 += __shfl_xor(dp0, 1, 64); dp0 += __shfl_xor(dp0, 2, 64);
-  dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64);
-  float p0 = 0.f, ds = 0.f;
-  if (v) {
-    const long si = ((long)b * H + hd) * N + q;
-    float e = s0 - a.lse[si] * kLog2e;
-    if (HAS_BIAS) e += a.bias_w * kLog2e * a.bias_u[(long)b * N] * (a.row_flag ? a.row_flag[(long)b * N + q] : 1.f);
-    p0 = __builtin_amdgcn_exp2f(e);
-    ds = p0 * (dp0 - dl);
-    if (part == 0) { a.delta[si] = dl; a.ds0[si] = ds; }
+#pragma unroll
+  for (int it = 0; it < PRE_IT; ++it) {
+    const int q = chunk * PRE_ROWS + 64 * it + row;
+    const bool v = q < N;
+    float s0 = 0.f, dp0 = 0.f, dl = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float qq = (float)qv[it][c2][j], dd = (float)dv[it][c2][j];
+        s0 = fmaf(qq, ks[8 * c2 + j], s0);
+        dp0 = fmaf(dd, v0f[8 * c2 + j], dp0);
+        dl = fmaf(dd, (float)ov[it][c2][j], dl);
+      }
+    s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
+    dp0 += __shfl_xor(dp0, 1, 64); dp0 += __shfl_xor(dp0, 2, 64);
+    dl += __shfl_xor(dl, 1, 64); dl += __shfl_xor(dl, 2, 64);
+    float p0 = 0.f, ds = 0.f;
+    if (v) {
+      const long si = ((long)b * H + hd) * N + q;
+      float e = s0 - a.lse[si] * kLog2e;
+      if (HAS_BIAS) e += b0 * (a.row_flag ? a.row_flag[(long)b * N + q] : 1.f);
+      p0 = __builtin_amdgcn_exp2f(e);
+      ds = p0 * (dp0 - dl);
+      if (part == 0) { a.delta[si] = dl; a.ds0[si] = ds; }
+    }
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        kk[8 * c2 + j] = fmaf(ds, (float)qv[it][c2][j], kk[8 * c2 + j]);
+        vv[8 * c2 + j] = fmaf(p0, (float)dv[it][c2][j], vv[8 * c2 + j]);
+      }
   }
-  // column sums over the block's 64 rows: lanes with equal `part` hold the same 16 head dims
+  // column sums over the block's rows: lanes with equal `part` hold the same 16 head dims
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    float kk = ds * qf[i], vv = p0 * dof[i];
+    float k1 = kk[i], v1 = vv[i];
 #pragma unroll
-    for (int o = 4; o < 64; o <<= 1) { kk += __shfl_xor(kk, o, 64); vv += __shfl_xor(vv, o, 64); }
-    if ((tid & 63) < 4) { red[wave][part * 16 + i] = kk; red[wave][64 + part * 16 + i] = vv; }
+    for (int o = 4; o < 64; o <<= 1) { k1 += __shfl_xor(k1, o, 64); v1 += __shfl_xor(v1, o, 64); }
+    if ((tid & 63) < 4) { red[wave][part * 16 + i] = k1; red[wave][64 + part * 16 + i] = v1; }
   }
   __syncthreads();
   if (tid < 128) a.kv0[(((long)b * H + hd) * a.nchunk + chunk) * 128 + tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);

@@ -12,7 +12,7 @@
 #include "common.h"
 #include "../../include/s4f.h"
 
-static_assert(sizeof(s4f_layer_desc) == 552, "s4f_layer_desc changed: update _lib.LayerDesc (ctypes mirror) with it");
+static_assert(sizeof(s4f_layer_desc) == 568, "s4f_layer_desc changed: update _lib.LayerDesc (ctypes mirror) with it");
 
 namespace {
 
@@ -137,7 +137,11 @@ S4F_API int s4f_encoder_layer_bwd(const s4f_layer_desc* p, s4f_stream stream, s4
     G g = dgrad(L.g1t, L.wo, L.wo_T, E, E, L.dctx, L.hint[6]);
     TRY(s4f_gemm(&g.d, stream));
   }
-  TRY(s4f_attention_bwd(L.qkv, L.ctx, L.dctx, L.lse, L.delta, L.dqkv, L.bias_u, L.row_flag, L.bias_w, L.B, L.N, L.H, T, stream));
+  if (bf && L.attn_ws)
+    TRY(s4f_attention_bwd_fused(L.qkv, L.ctx, L.dctx, L.lse, L.delta, L.dqkv, L.bias_u, L.row_flag, L.bias_w, L.B, L.N, L.H, L.attn_ws,
+                                L.attn_ws_bytes, stream));
+  else
+    TRY(s4f_attention_bwd(L.qkv, L.ctx, L.dctx, L.lse, L.delta, L.dqkv, L.bias_u, L.row_flag, L.bias_w, L.B, L.N, L.H, T, stream));
   // the four weight gradients of the layer as ONE grouped launch (+ the in_proj bias column sums) beside the chain
   TRY(fork());
   {

@@ -377,6 +377,23 @@ class PatchEmbedFn(Function):
 # stays: it is what runs under the profiler (bench.py's per-GEMM roofline accounting needs one event pair per GEMM), with
 # S4F_FUSED_LAUNCH=0, and for GEMM signatures the shipped tuning table does not know yet (they are tuned there on first use).
 FUSED_LAUNCH = os.environ.get('S4F_FUSED_LAUNCH', '1') != '0'
+# Round 4: attention backward as ONE sweep over the scores (s4f_attention_bwd_fused, bf16 mode; `=0`: the two-kernel form).  Its
+# workspace (the fp32 dQ slabs: 204 MB at 16 images x 1025 tokens) is ONE buffer per device shared by all layers: the backward of
+# the layers is serial on the chain's stream, and the buffer holds nothing between two calls.
+ATTN_BWD_FUSED = os.environ.get('S4F_ATTN_BWD_FUSED', '1') != '0'
+_ATTN_WS = {}
+
+
+def _attn_bwd_ws(Bn, N, H, device):
+    need = K.attention_bwd_ws_bytes(Bn, N, H)
+    key = (device.type, device.index)
+    ws = _ATTN_WS.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=device, dtype=torch.uint8)
+        _ATTN_WS[key] = ws
+    ws.record_stream(torch.cuda.current_stream(device))
+    return ws
+
 _LAYER_PLANS = {}
 
 
@@ -524,6 +541,7 @@ class LayerFn(Function):
         dctx = torch.empty(M, E, device=dev, dtype=T)
         dqkv = torch.empty(M, 3 * E, device=dev, dtype=T)
         delta = torch.empty(Bn, H, N, device=dev)
+        attn_ws = _attn_bwd_ws(Bn, N, H, dev) if (code == BF16 and ATTN_BWD_FUSED) else None
         dxn = torch.empty(M, E, device=dev, dtype=T)
         g0 = torch.empty(Bn, N, E, device=dev, dtype=R)
         g0t = torch.empty(Bn, N, E, device=dev, dtype=T) if (code == BF16 and R != T) else None
@@ -539,6 +557,7 @@ class LayerFn(Function):
             d.g2, d.g2t, d.g2cs = g2.data_ptr(), g2t.data_ptr(), _lp(g2cs)
             d.dz, d.dxn2, d.g1, d.g1t, d.dctx, d.dqkv, d.delta, d.dxn = dz.data_ptr(), dxn2.data_ptr(), g1.data_ptr(), g1t.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), delta.data_ptr(), dxn.data_ptr()
             d.g0, d.g0t, d.g0cs = g0.data_ptr(), (g0t if g0t is not None else g0).data_ptr(), g0cs.data_ptr()
+            d.attn_ws, d.attn_ws_bytes = (attn_ws.data_ptr(), attn_ws.numel()) if attn_ws is not None else (None, 0)
             use_side = USE_SIDE_STREAM and LAYER_WG_SIDE
             side = side_stream(dev) if use_side else None
             L.call('s4f_encoder_layer_bwd', d, L.stream(), side.cuda_stream if side is not None else None, ev.cuda_event if side is not None else None)
@@ -568,8 +587,12 @@ class LayerFn(Function):
                             store.grad_phys(b2), M, E, code, dcolsum=store.grad_phys(bo))
             # ---- attention
             _dgrad(g1t, wo, M, E, E, store, code, out_t=dctx, ldo_t=E)
-            K.attention_bwd(sv['qkv'], sv['ctxv'], dctx, sv['lse'], delta, dqkv, Bn, N, H, code, bias_u=sv['bias_u'],
-                            row_flag=sv['row_flag'], bias_w=bias_w)
+            if attn_ws is not None:
+                K.attention_bwd_fused(sv['qkv'], sv['ctxv'], dctx, sv['lse'], delta, dqkv, Bn, N, H, attn_ws, bias_u=sv['bias_u'],
+                                      row_flag=sv['row_flag'], bias_w=bias_w)
+            else:
+                K.attention_bwd(sv['qkv'], sv['ctxv'], dctx, sv['lse'], delta, dqkv, Bn, N, H, code, bias_u=sv['bias_u'],
+                                row_flag=sv['row_flag'], bias_w=bias_w)
             with on_side(dev, dqkv, xn, dz, xn2, g1t, ctxv, g2t, a_act, enable=LAYER_WG_SIDE):
                 K.wgrad_grouped([(dz, xn2, F_, E, M, store.grad_phys(w1)),
                                  (g2t, a_act, E, F_, M, store.grad_phys(w2)),
