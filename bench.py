@@ -348,7 +348,7 @@ def main():
                                 dist_backend=dist.get_backend() if world > 1 else None,
                                 ranks_seen=dist.get_world_size() if world > 1 else 1,
                                 grad_collectives_per_step=round(grad_collectives, 2) if grad_collectives else None,
-                                stream_layout_check=getattr(reducer, 'stream_layout', None)),
+                                fused_zero_grad=bool(getattr(opt, 'fused_zero_grad', False))),
                     roofline=roofline, cpu_baseline=cpu, losses=losses, mask_ratio=mask_ratio,
                     host_enqueue_ms_per_step=round(1e3 * host_dt / args.steps, 3),
                     host_enqueue_idle_queue_ms=round(host_idle_ms, 3))

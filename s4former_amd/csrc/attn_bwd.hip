@@ -836,10 +836,12 @@ S4F_API int s4f_attention_bwd_fused(const void* qkv, const void* ctx, const void
   if (a.nkb > 0) {
     const dim3 grid(a.nkb * H * B);
     if (bias_u) {
-      hipFuncSetAttribute((const void*)fb::main_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, fb::LDS_TOTAL);
+      static std::atomic<uint64_t> attr_t{0};
+      s4f_set_max_lds(attr_t, (const void*)fb::main_kernel<true>, fb::LDS_TOTAL);
       hipLaunchKernelGGL(fb::main_kernel<true>, grid, dim3(256), fb::LDS_TOTAL, st, a);
     } else {
-      hipFuncSetAttribute((const void*)fb::main_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, fb::LDS_TOTAL);
+      static std::atomic<uint64_t> attr_f{0};
+      s4f_set_max_lds(attr_f, (const void*)fb::main_kernel<false>, fb::LDS_TOTAL);
       hipLaunchKernelGGL(fb::main_kernel<false>, grid, dim3(256), fb::LDS_TOTAL, st, a);
     }
   }

@@ -183,3 +183,16 @@ __device__ __forceinline__ void gelu_pair(float z, float& y, float& dy) {
 }
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: set it once per (kernel, device), not
+// once per process.  `mask` is a function-local static std::atomic<uint64_t> of the call site (one bit per device; a lost
+// race only repeats the idempotent call).
+#include <atomic>
+static inline void s4f_set_max_lds(std::atomic<uint64_t>& mask, const void* kernel, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const uint64_t bit = 1ull << (dev & 63);
+  if (mask.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  mask.fetch_or(bit, std::memory_order_release);
+}

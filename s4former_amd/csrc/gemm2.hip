@@ -671,12 +671,9 @@ int launch(const s4f_gemm_desc& d, hipStream_t st) {
   a.sk = sk;
   a.zgroup = (BMo == S4F_OP_K_CONV && sk > 1) ? 1 : 0;
   const size_t shm = smem_bytes<BN, AM, BMo, NW>();
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_set{0};       // one bit per device
   auto kern = gemm2_kernel<BN, AM, BMo, NW>;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
+  s4f_set_max_lds(attr_set, (const void*)kern, (int)shm);
   dim3 grid(a.tiles_m * a.tiles_n, 1, a.zgroup ? 8 * ceil_div(sk, 8) : sk);
   hipLaunchKernelGGL(kern, grid, dim3(64 * NW), shm, st, a);
   return 0;
@@ -705,12 +702,9 @@ int launch_grouped(const s4f_gemm_desc* ds, int count, hipStream_t st) {
     g.tile_end[i] = total;
   }
   const size_t shm = smem_bytes<BN, AM, BMo, NW>();
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_set{0};       // one bit per device
   auto kern = gemm2_grouped_kernel<BN, AM, BMo, NW>;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
+  s4f_set_max_lds(attr_set, (const void*)kern, (int)shm);
   hipLaunchKernelGGL(kern, dim3(total, 1, zmax), dim3(64 * NW), shm, st, g);
   return 0;
 }

@@ -353,8 +353,9 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
   // tensor: the fc2 input gradient): the tile is staged ONCE as bf16 by all eight waves together (135 KiB) and leaves in
   // 16-byte rows - one barrier pair instead of two, half the LDS bytes of the fp32 staging.  The activations are applied
   // in the read-out to the bf16-rounded pre-activation (one more rounding to 8 bits before an 8-bit output).
-  // (round 3: a bf16 residual - resid_t - is added in the read-out: out = bf16(bf16(acc + bias) + resid), the proj / fc2 GEMMs)
-  const bool plain_t = wide && d.out_t && !d.out_f32 && (!d.resid || d.resid_t) && !d.pos && !d.atomic &&
+  // (round 3: a bf16 residual - resid_t - is added in the read-out: out = bf16(bf16(acc + bias) + resid), the proj / fc2 GEMMs;
+  //  only without an activation: with one the descriptor takes the generic fp32-staged path below, which applies both)
+  const bool plain_t = wide && d.out_t && !d.out_f32 && (!d.resid || (d.resid_t && d.act == S4F_ACT_NONE)) && !d.pos && !d.atomic &&
                        (d.act == S4F_ACT_NONE ? !d.out_pre : true);
   if (plain_t) {
     constexpr int LDB = 256 + 8;                     // staged row = 528 B
@@ -543,12 +544,9 @@ int launch5(const s4f_gemm_desc& d, hipStream_t st) {
   const long b_bytes = ((long)(d.N - 1) * d.ldb + d.K) * 2;
   if (d.K % BK != 0 || a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return -100;
   const size_t shm = 2 * (size_t)G5_BUF + 2 * (size_t)G5_TAILB;     // 144 KiB (epilogue staging tile: 130 KiB)
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_set{0};       // one bit per device
   auto kern = gemm5_kernel<AMODE, DBG>;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
+  s4f_set_max_lds(attr_set, (const void*)kern, (int)shm);
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, 1, sk), dim3(512), shm, st, a);
   return 0;
 }

@@ -385,12 +385,9 @@ int launch6(const s4f_gemm_desc& d, hipStream_t st) {
   GemmArgs a;
   if (!fill_args(a, d)) return -100;
   const size_t shm = 2 * (size_t)G6_BUF + 4096;        // 132 KiB (epilogue staging tile: 130 KiB)
-  static bool attr_set = false;
+  static std::atomic<uint64_t> attr_set{0};       // one bit per device
   auto kern = gemm6_kernel<BMODE>;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
+  s4f_set_max_lds(attr_set, (const void*)kern, (int)shm);
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n * a.sk), dim3(512), shm, st, a);
   return 0;
 }
@@ -405,11 +402,8 @@ int launch6_grouped(const s4f_gemm_desc* ds, int count, hipStream_t st) {
     g.work_end[i] = total;
   }
   const size_t shm = 2 * (size_t)G6_BUF + 4096;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)gemm6_grouped_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_set{0};       // one bit per device
+  s4f_set_max_lds(attr_set, (const void*)gemm6_grouped_kernel, (int)shm);
   hipLaunchKernelGGL(gemm6_grouped_kernel, dim3(total), dim3(512), shm, st, g);
   return 0;
 }

@@ -1756,12 +1756,9 @@ S4F_API int s4f_bn_relu_cls_fwd(const void* y, const float* scale, const float* 
   int grid = ceil_div(ceil_div(npix, 16), 4 * 4);
   if (grid > 2048) grid = 2048;
   if (shm > 48 * 1024) {          // (C = 512 in fp32: 70 KB of dynamic LDS)
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute((const void*)bn_relu_cls_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      hipFuncSetAttribute((const void*)bn_relu_cls_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-      attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_b{0}, attr_f{0};      // one bit per device
+    s4f_set_max_lds(attr_b, (const void*)bn_relu_cls_fwd_kernel<bf16_t>, 96 * 1024);
+    s4f_set_max_lds(attr_f, (const void*)bn_relu_cls_fwd_kernel<float>, 96 * 1024);
   }
   if (dtype == S4F_BF16) hipLaunchKernelGGL(bn_relu_cls_fwd_kernel<bf16_t>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const bf16_t*)y, scale, shift, (const bf16_t*)seg_w, seg_b, logits, ld_logits, (bf16_t*)feat, (long)npix, C, ncls);
   else hipLaunchKernelGGL(bn_relu_cls_fwd_kernel<float>, dim3(grid), dim3(256), shm, (hipStream_t)stream, (const float*)y, scale, shift, (const float*)seg_w, seg_b, logits, ld_logits, (float*)feat, (long)npix, C, ncls);
@@ -1815,14 +1812,11 @@ S4F_API int s4f_upce_bwd(const float* logits_lo, const uint8_t* labels, const fl
     hipStream_t st = (hipStream_t)stream;
     const int c4n = ceil_div(C, 4);
     const size_t shm = (size_t)(18 * 18 * 4 * c4n + (C > 4 * c4n - 2 ? C : 4 * c4n - 2) * 256) * sizeof(float);   // halo + one-hot columns: 53.6 KB at 21 classes = three blocks per CU
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipFuncSetAttribute((const void*)upce_bwd_lse_kernel<bf16_t, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      hipFuncSetAttribute((const void*)upce_bwd_lse_kernel<bf16_t, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      hipFuncSetAttribute((const void*)upce_bwd_lse_kernel<float, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      hipFuncSetAttribute((const void*)upce_bwd_lse_kernel<float, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      attr_set = true;
-    }
+    static std::atomic<uint64_t> attr_u[4] = {{0}, {0}, {0}, {0}};      // one bit per device
+    s4f_set_max_lds(attr_u[0], (const void*)upce_bwd_lse_kernel<bf16_t, 2>, 80 * 1024);
+    s4f_set_max_lds(attr_u[1], (const void*)upce_bwd_lse_kernel<bf16_t, 4>, 80 * 1024);
+    s4f_set_max_lds(attr_u[2], (const void*)upce_bwd_lse_kernel<float, 2>, 80 * 1024);
+    s4f_set_max_lds(attr_u[3], (const void*)upce_bwd_lse_kernel<float, 4>, 80 * 1024);
     if (dtype == S4F_BF16) {
       if (s == 2) hipLaunchKernelGGL((upce_bwd_lse_kernel<bf16_t, 2>), dim3(nblk), dim3(256), shm, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, ignore_index);
       else hipLaunchKernelGGL((upce_bwd_lse_kernel<bf16_t, 4>), dim3(nblk), dim3(256), shm, st, logits_lo, labels, lse, gscale, gscale_dev, dlo, (bf16_t*)dlo_t, B, h, w, C, ldc, ignore_index);

@@ -63,7 +63,6 @@ class GradReducer:
         self._handles = []
         self._done = []          # ranges already launched in this step
         self._store = None
-        self.stream_layout = None    # result of functional.check_stream_layout (N > 1 on GPUs)
         self.launches = 0            # collectives issued so far (bench.py reports the per-step count)
 
     def attach(self, store):
@@ -145,11 +144,12 @@ def setup_data_parallel(model, optimizer, device, reducer=None):
     build the arenas, make the replicas identical (broadcast of rank 0's student and teacher arenas), hook the gradient
     reducer into the per-range `range_done` notifications and, unless S4F_EAGER_SGD=0, the optimiser's eager per-range step.
 
-    N > 1 defaults: per-range all-reduce during backward, the SGD of a range behind its all-reduce, and the first-use order
-    of the streams that puts the communication on the weight-gradient stream's hardware queue (functional.lay_out_streams;
-    S4F_STREAM_LAYOUT=0 turns it off).  Still opt-in, because they change the ORDER in which collectives are issued and no
-    run with peers exists yet: S4F_AUX_LOCKSTEP=1 / S4F_DECODE_LOCKSTEP=1 (heads advancing in lockstep, one SyncBN exchange
-    per layer for all of them; another -0.45 ms in the one-rank RCCL run).
+    N > 1 defaults: all-reduce of a span of the gradient arena during backward as soon as it is final (three encoder layers per
+    bucket; a head group as soon as its last range has reported: ParamStore.range_done), the SGD of a span behind its
+    all-reduce, both on a communication stream of the reducer's own, and the heads advancing in lockstep
+    (S4F_AUX_LOCKSTEP / S4F_DECODE_LOCKSTEP = auto: one SyncBN exchange per head layer for all of them).  None of it has run
+    with a peer on hardware yet.  (Round 2 - 3 also bound the communication to the weight-gradient stream's
+    hardware queue by the streams' first-use order; its own self-check never passed on any box and the path was removed.)
     Returns the reducer; per step:  backward -> join_side_streams() -> reducer.reduce_(store.grad) -> reducer.wait() ->
     optimizer.step(grad_scale=reducer.grad_scale())."""
     reducer = reducer if reducer is not None else GradReducer()
@@ -165,19 +165,6 @@ def setup_data_parallel(model, optimizer, device, reducer=None):
         # three encoder layers (3 x 7.09 M fp32 = 85 MB) per gradient bucket: 4 all-reduces for the backbone during backward
         # + the rest (heads, patch embedding) in 128 MB buckets at the end, instead of one collective per layer and head (41)
         model.student_store.coalesce_min = int(os.environ.get('S4F_BUCKET_MIN_ELEMS', str(20_000_000)))
-    if collectives_active() and os.environ.get('S4F_STREAM_LAYOUT', '1') != '0' and torch.device(device).type == 'cuda':
-        # ON by default since round 2: measured through RCCL itself (one-rank group, tools/exp/rccl_world1.py) the step costs
-        # 33.95 ms with the streams bound to hardware queues in whatever order they are first used and 32.58 ms with this
-        # order (30.75 ms without any process group).  It changes which streams share a queue, never what runs or in which
-        # order the collectives are issued.
-        from .functional import lay_out_streams, check_stream_layout
-        side = lay_out_streams(device)
-        # the layout rests on the runtime binding streams to its hardware queues in first-use order (undocumented): verify the
-        # property it is meant to give - the chain, the two head streams and the weight-gradient stream do not serialise each
-        # other - with two concurrent spin kernels per pair, and fall back to a communication stream of its own otherwise
-        reducer.stream_layout = check_stream_layout(device)
-        if reducer.stream_layout.get('ok', False):
-            reducer._stream = side                     # collectives + eager SGD issue from the weight-gradient stream
     if os.environ.get('S4F_EAGER_SGD', '1') != '0':
         # parameter ranges are updated as soon as their (all-reduced) gradient is final, behind the rest of backward
         optimizer.attach_eager(model.student_store, reducer if collectives_active() else None, reducer.grad_scale())

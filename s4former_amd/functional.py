@@ -58,32 +58,6 @@ def head_stream(device, name, priority=0):
     return _head[key]
 
 
-def lay_out_streams(device):
-    """The N > 1 default since round 2 (dist.setup_data_parallel; S4F_STREAM_LAYOUT=0 turns it off).  First inferred on one-GPU
-    boxes with a stand-in for RCCL's stream (tools/exp/queue_map.py, tools/exp/rehearsal.py), then measured through RCCL
-    itself with a one-rank process group (tools/exp/rccl_world1.py: 33.95 -> 32.58 ms per step); not yet with peers.
-    N > 1 only, after the first collective (RCCL's stream has then been USED first).  The runtime has FOUR hardware
-    queues; the default stream owns queue 1 and every other stream is bound at its first use, in the fixed pattern
-    2 3 4 4 3 2 1 4 ... (tools/exp/queue_map.py); two streams on one queue serialise.  Wanted: the chain alone on queue 1,
-    the decode / auxiliary head streams alone on queues 3 / 4, and the weight-gradient stream - which then also issues the
-    gradient all-reduces and the eager SGD - on queue 2 WITH RCCL's stream: both are off the critical chain.  First-use
-    order RCCL, decode, aux, two throw-away streams, side gives exactly that (rehearsed on one GPU with a stand-in for
-    RCCL: S4F_STREAM_LAYOUT=test); left alone, the weight gradients (4th stream used) share queue 4 with the auxiliary
-    heads.  Returns the side stream (the reducer's communication stream).  A wrong guess only changes who shares."""
-    def touch(st):
-        with torch.cuda.stream(st):
-            torch.empty(64, device=device).fill_(0.0)
-
-    if torch.device(device).index not in _side:
-        touch(head_stream(device, 'decode'))
-        touch(head_stream(device, 'aux'))
-        for _ in range(2):
-            _burn.append(torch.cuda.Stream(device=device))
-            touch(_burn[-1])
-        touch(side_stream(device))
-    return side_stream(device)
-
-
 _burn = []
 
 

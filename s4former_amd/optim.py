@@ -59,6 +59,14 @@ class S4FSGD(torch.optim.Optimizer):
         self._plan_cache = (store, plan)
         return store, plan
 
+    def _plan_covers_all_params(self, store, plan):
+        key = id(plan)
+        if getattr(self, '_cover_cache', (None, None))[0] != key:
+            ok = all(any(a <= e.off and e.off + e.numel <= b for _, a, b, _ in plan)
+                     for e in store.entries if e.is_param and e.module._parameters[e.attr].requires_grad)
+            self._cover_cache = (key, ok)
+        return self._cover_cache[1]
+
     # ------------------------------------------------------------------ eager mode
     def attach_eager(self, store, reducer=None, grad_scale=1.0):
         """Step every arena range as soon as its gradient is final (ParamStore.range_done: the end of an encoder layer's
@@ -152,7 +160,9 @@ class S4FSGD(torch.optim.Optimizer):
                     K.sgd_momentum(store.flat[e.off:e.off + n], store.grad[e.off:e.off + n], store.mom[e.off:e.off + n], pt,
                                    n, g['lr'], g['momentum'], grad_scale, first, store.dtype, zero_grad=self.fused_zero_grad)
         store.first_sgd_step = False
-        store.grad_clean = bool(self.fused_zero_grad)      # every parameter range has been consumed and zeroed
+        # every parameter range of the plan has been consumed and zeroed; the flag may only be raised if the plan really covers every
+        # trainable parameter of the arena (a gradient outside it would survive the skipped zero_grad() and accumulate silently)
+        store.grad_clean = bool(self.fused_zero_grad) and self._plan_covers_all_params(store, plan)
         if store.flat_t is not None and store._T_items:
             store.sync_T(eager=True)      # transposed operand shadows follow the bf16 shadow the SGD kernels just wrote
         return loss

@@ -297,6 +297,7 @@ class ParamStore:
     def node_done(self):
         """called by every autograd node of this replica at the end of its backward (hook for the data-parallel
         gradient reducer: when the last pending node has run, the gradient arena is final)"""
+        self.grad_clean = False                      # a node has accumulated into the gradient arena (also nodes that never range_acquire)
         cb = getattr(self, 'on_node_done', None)
         if cb is not None:
             cb()
@@ -314,9 +315,10 @@ class ParamStore:
 
         coalesce_min > 0 (set by dist.setup_data_parallel at N > 1): ranges are MERGED with their already-final neighbours of the
         same parameter group and handed on only when the merged span reaches coalesce_min elements - three encoder layers per
-        bucket instead of one all-reduce (and one SGD launch) per layer: 41 -> <= 8 collectives per step.  What never
-        reaches the size (heads, the first layers) is left to GradReducer.reduce_() / optimizer.step(), which cover every
-        range not handed on."""
+        bucket instead of one all-reduce (and one SGD launch) per layer: 41 -> <= 8 collectives per step.  A group whose last
+        pending range has reported is flushed whatever its size (the heads: their collectives run under the backbone's
+        backward); anything never reported at all is left to GradReducer.reduce_() / optimizer.step(), which cover every range
+        not handed on."""
         cb = getattr(self, 'on_range_done', None)
         if cb is None:
             return
@@ -346,6 +348,18 @@ class ParamStore:
             cb(a, b)
         else:
             self._co.append((a, b))
+        # round 4: a parameter group none of whose ranges is still pending (no node of this step will write into it any more) is
+        # handed on AT ONCE, whatever its size - the reference's DDP reducer fires a bucket as soon as it is ready
+        # (mmseg/apis/train.py:129-138).  The decode head (3.5 M) and the auxiliary heads (9.5 M) never reach coalesce_min; parked
+        # until reduce_() their all-reduce + SGD sat on the critical path behind the whole backward although their gradients are
+        # final before the backbone's backward starts.
+        pend = getattr(self, '_pend', None) or {}
+        if not any(ga <= pa and pb <= gb for (pa, pb) in pend):
+            mine = sorted(sp for sp in self._co if ga <= sp[0] and sp[1] <= gb)
+            if mine:
+                self._co = [sp for sp in self._co if not (ga <= sp[0] and sp[1] <= gb)]
+                for sa, sb in mine:
+                    cb(sa, sb)
 
     # A range is FINAL when the last node that accumulates into it has run its backward.  A node announces itself in its
     # forward (range_acquire) and signs off at the end of its backward (range_release); the counts restart with every step

@@ -53,14 +53,22 @@ def _worker(rank, world, port, q):
     launched = []
     issue0 = GradReducer.issue
     red3.issue = lambda t: (launched.append(t.numel()), issue0(t))[1]
-    ps.range_done(240_000, 270_016)                    # a head: below the size, own group
-    for k in range(11, -1, -1):                         # twelve "layers" of 20,000 elements, last first
-        ps.range_done(k * 20_000, (k + 1) * 20_000)
+    # forward: every node announces its range (heads last, as in the model); backward: the heads sign off first
+    layer_rngs = [(k * 20_000, (k + 1) * 20_000) for k in range(12)]
+    head_rngs = [(240_000, 250_000), (250_000, 300_032)]                 # "decode head", "auxiliary heads": both far below the size
+    for rng in layer_rngs + head_rngs:
+        ps.range_acquire(rng)
+    ps.range_release(head_rngs[0])                     # first head final: its group still has a pending range -> parked
+    parked = list(launched)
+    ps.range_release(head_rngs[1])                     # group complete: handed on although 60,032 < ... regardless of the size
+    heads_done = list(launched)
+    for rng in reversed(layer_rngs):                    # twelve "layers" of 20,000 elements, last first
+        ps.range_release(rng)
     early = list(launched)
     red3.reduce_(ps.grad)
     red3.wait()
     res['grad3'] = (ps.grad * red3.grad_scale()).clone()
-    res['buckets3'] = (early, list(launched))
+    res['buckets3'] = (early, list(launched), parked, heads_done)
     # 2. parameters broadcast from rank 0
     p = torch.full((1000,), float(rank))
     red.broadcast_(p, src=0)
@@ -110,9 +118,13 @@ def test_world2_gloo():
     k0 = torch.randn(300_032, generator=torch.Generator().manual_seed(300))
     k1 = torch.randn(300_032, generator=torch.Generator().manual_seed(301))
     assert torch.allclose(out[0]['grad3'], (k0 + k1) / 2, atol=1e-6) and torch.equal(out[0]['grad3'], out[1]['grad3'])
-    early, all_ = out[0]['buckets3']
-    assert early == [60_000] * 4, early                   # 12 layers -> 4 buckets of 3 during "backward", nothing for the small head
-    assert sum(all_) == 300_032 and len(all_) <= 6, all_  # every element exactly once, the rest in one more bucket
+    early, all_, parked, heads_done = out[0]['buckets3']
+    # round 4: a head group is handed to the reducer as soon as its LAST range is final - before the first backbone bucket -
+    # whatever its size; 12 layers -> 4 buckets of 3 during "backward"
+    assert parked == [], parked
+    assert sum(heads_done) == 60_032 and len(heads_done) <= 2, heads_done
+    assert early[:len(heads_done)] == heads_done and early[len(heads_done):] == [60_000] * 4, early
+    assert sum(all_) == 300_032 and len(all_) == len(early), all_   # every element exactly once, nothing left for reduce_()
     assert out[0]['bcast'] == 0.0 and out[1]['bcast'] == 0.0
     # local loss stays local (it is what backward runs on); logged values are the rank mean
     assert out[0]['loss_local'] == 1.5 and out[1]['loss_local'] == 3.0

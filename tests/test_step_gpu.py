@@ -326,6 +326,38 @@ def test_lockstep_heads_match_the_sequential_heads(name, monkeypatch):
             assert abs(a['gn'][n] - b['gn'][n]) <= (1e-4, 1e-3)[it] * a['gn'][n] + 1e-9, (it, n, a['gn'][n], b['gn'][n])
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_launch_paths_of_the_encoder_layer_agree(dtype, monkeypatch):
+    """The encoder layer has two launch paths that issue the same kernels: one C-ABI call per layer forward / backward
+    (s4f_encoder_layer_fwd / _bwd from a descriptor, csrc/layer.hip: the default) and the per-kernel Python path of
+    functional.LayerFn (profiler runs, untuned GEMM signatures, S4F_FUSED_LAUNCH=0) - plus the grouped weight gradient on the side
+    stream or inside the chain, and (bf16) the one-sweep or the two-kernel attention backward.  Operand order, leading
+    dimensions, the fc1 column-sum fold and the stream forks are written twice; this test holds every combination to the default:
+    losses and every parameter gradient (fp32: to atomics noise; bf16: the two attention backward forms round differently)."""
+    from s4former_amd import functional as F_
+    z, meta = load_gold('mt_pasa')
+    recs = {}
+    combos = [(True, True, True), (False, True, True), (True, False, True), (False, False, True)]
+    if dtype == 'bf16':
+        combos += [(True, True, False), (False, True, False)]
+    for fused, side, sweep in combos:
+        monkeypatch.setattr(F_, 'FUSED_LAUNCH', fused)
+        monkeypatch.setattr(F_, 'LAYER_WG_SIDE', side)
+        monkeypatch.setattr(F_, 'ATTN_BWD_FUSED', sweep)
+        model, opt, sched = build_product(meta, dtype)
+        recs[(fused, side, sweep)] = run_product(model, opt, sched, meta, iters=1)[0]
+    ref = recs[(True, True, True)]
+    for key, r in recs.items():
+        tight = dtype == 'fp32' or key[2]
+        for k in ref['log']:
+            tol = 1e-5 if tight else 2e-3
+            assert abs(float(r['log'][k]) - float(ref['log'][k])) <= tol * abs(float(ref['log'][k])) + 1e-7, (key, k)
+        assert set(r['gn']) == set(ref['gn'])
+        for n in ref['gn']:
+            tol = (1e-4 if dtype == 'fp32' else 2e-3) if tight else 2e-2
+            assert abs(r['gn'][n] - ref['gn'][n]) <= tol * ref['gn'][n] + 1e-9, (key, n, r['gn'][n], ref['gn'][n])
+
+
 def test_unfused_two_pass_step_with_eager_sgd():
     """A batch WITHOUT a 'sup' group takes the unfused foward_unsup_train path: with attn_mask_seperate_head every encoder layer
     runs twice in one step (masked + plain student pass).  A layer's arena range must be reported final after the SECOND

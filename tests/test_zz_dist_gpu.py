@@ -110,7 +110,6 @@ VARIANTS = {
     'default': {},
     'no_eager_sgd': dict(S4F_EAGER_SGD='0'),
     'lockstep_heads': dict(S4F_AUX_LOCKSTEP='1', S4F_DECODE_LOCKSTEP='1'),
-    'no_stream_layout': dict(S4F_STREAM_LAYOUT='0'),
     # round 3: final ranges merged two tiny layers at a time (the production size merges three DeiT-B layers), and the round-2
     # schedule (one head after the other, one collective per range) now that lockstep + coalescing are the N > 1 defaults
     'coalesced_buckets': dict(S4F_BUCKET_MIN_ELEMS='1500000'),
@@ -119,7 +118,7 @@ VARIANTS = {
 
 
 @pytest.mark.parametrize('variant,flags', [('default', 'pasa'), ('default', 'plain'), ('no_eager_sgd', 'pasa'),
-                                           ('lockstep_heads', 'pasa'), ('no_stream_layout', 'plain'), ('coalesced_buckets', 'pasa'),
+                                           ('lockstep_heads', 'pasa'), ('coalesced_buckets', 'pasa'),
                                            ('round2_schedule', 'plain')])
 def test_two_ranks_equal_one_rank_on_the_concatenated_batch(variant, flags, single, tmp_path):
     d = str(tmp_path)

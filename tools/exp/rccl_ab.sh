@@ -26,4 +26,4 @@ run default A=1 &&
 run aux_lockstep S4F_AUX_LOCKSTEP=1 &&
 run aux_decode_lockstep S4F_AUX_LOCKSTEP=1 S4F_DECODE_LOCKSTEP=1 &&
 run no_eager_sgd S4F_EAGER_SGD=0 &&
-run lockstep_layout S4F_AUX_LOCKSTEP=1 S4F_DECODE_LOCKSTEP=1 S4F_STREAM_LAYOUT=1
+run lockstep_layout S4F_AUX_LOCKSTEP=1 S4F_DECODE_LOCKSTEP=1

@@ -63,7 +63,6 @@ if __name__ == '__main__':
     argv = sys.argv[1:]
     if '--layout' in argv:
         argv.remove('--layout')
-        os.environ['S4F_STREAM_LAYOUT'] = '1'
     if '--' in argv:
         argv.remove('--')
     D.collectives_active = lambda: True
