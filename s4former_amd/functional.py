@@ -404,6 +404,8 @@ def _layer_plan(store, prm, M, E, F_, H, code, R):
         wg = (int(ch[0]), int(ch[1]))
     elif code == BF16:
         wg = (4, wg[1])
+    if os.environ.get('S4F_WG_SPLITK'):      # experiment: k-ranges of the layer's grouped weight gradient (108 tiles x k-ranges blocks)
+        wg = (wg[0], int(os.environ['S4F_WG_SPLITK']))
     d = L_.LayerDesc()
     d.E, d.F, d.H, d.dtype, d.xdtype = E, F_, H, code, (BF16 if rt else F32)
     for i in range(8):
