@@ -25,6 +25,10 @@ SKIP_MASKED_COPY = os.environ.get('S4F_SKIP_MASKED_COPY', '1') != '0'     # A/B 
 FUSE_CLS_FWD = os.environ.get('S4F_FUSE_CLS_FWD', '1') != '0'             # A/B switch: BN + ReLU + conv_seg forward in one pass
 FUSE_CLS_WGRAD = os.environ.get('S4F_FUSE_CLS_WGRAD', '1') != '0'         # A/B switch: conv_seg weight gradient inside the BN statistics pass (no stored activation)
 FUSE_CLS_GRAD = os.environ.get('S4F_FUSE_CLS_GRAD', '1') != '0'           # A/B switch: conv_seg input gradient inside the BN backward passes
+# experiment (round 4, verdict item 6): the LAST stage of an inference-only head pass (the teacher's pseudo-label path) with fp32
+# operands inside a bf16 run - the last conv's output is kept in fp32 and BN + ReLU + conv_seg run on it with the fp32 master
+# conv_seg weights.  Measured label flip rate against the reference: DESIGN A.15.  Off by default.
+TEACHER_LAST_FP32 = os.environ.get('S4F_TEACHER_LAST_FP32', '0') != '0'
 LOGIT_LD = 32   # channel stride of the low-resolution logits buffers (>= num_classes, multiple of 8)
 
 # ---------------------------------------------------------------------------------------------- side stream
@@ -704,7 +708,13 @@ def _head_forward_gen(tokens, hp, store, training, save, ex):
         Mp = Bn * h * w
         y = torch.empty(Mp, Cc, device=dev, dtype=T)
         sums, stats_done = None, False
-        if code == BF16 and _tiles256(Mp, Cc) < 96:
+        last_f32 = (TEACHER_LAST_FP32 and code == BF16 and k == nconv - 1 and not save and not training and FUSE_CLS_FWD
+                    and Cc % 32 == 0 and Cc <= 512 and hp['num_classes'] <= 32)
+        if last_f32:
+            y = torch.empty(Mp, Cc, device=dev)
+            K.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_f32=y, ldo_f32=Cc,
+                   conv=(Bn, h, w, cin, 1))
+        elif code == BF16 and _tiles256(Mp, Cc) < 96:
             # few output tiles (the 32x32 stage): split the 9*cin contraction over blocks, fp32 partial sums
             yf = torch.zeros(Mp, Cc, device=dev)
             K.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_f32=yf,
@@ -740,8 +750,12 @@ def _head_forward_gen(tokens, hp, store, training, save, ex):
             # it rebuilds (FUSE_CLS_WGRAD)
             keep_u = save and not (FUSE_CLS_WGRAD and _fuse_cls_ok(s, Cc, hp['num_classes']))
             u = torch.empty(Mp, Cc, device=dev, dtype=T) if keep_u else None
-            K.bn_relu_cls_fwd(y, scale, shift, store.shadow(hp['seg_w']), store.phys(hp['seg_b']), logits, LOGIT_LD, u, Mp, Cc,
-                              hp['num_classes'], code)
+            if last_f32:
+                K.bn_relu_cls_fwd(y, scale, shift, store.phys(hp['seg_w']), store.phys(hp['seg_b']), logits, LOGIT_LD, None, Mp, Cc,
+                                  hp['num_classes'], 0)
+            else:
+                K.bn_relu_cls_fwd(y, scale, shift, store.shadow(hp['seg_w']), store.phys(hp['seg_b']), logits, LOGIT_LD, u, Mp, Cc,
+                                  hp['num_classes'], code)
         else:
             u = torch.empty(Bn * h * s * w * s, Cc, device=dev, dtype=T)
             K.bn_relu_up_fwd(y, scale, shift, u, Bn, h, w, Cc, s, code)

@@ -155,7 +155,7 @@ def check_grad_samples(z, it, named_grads, tol, msgs, label='', rec=None, mtol=N
     """Element-wise comparison of EVERY parameter's gradient with the golden samples, relative to the tensor's largest element.
 
     Iteration 0 is held against the reference's FLOAT64 evaluation of the same step (`it0_gs64`): |got - ref64| <= max(tol, 8 D)
-    where D is the distance of the reference's OWN fp32 gradients from that fp64 evaluation (worst tensor).  On the tiny fixtures
+    for the worst tensor and <= max(tol, 3 D) for the 90th percentile over tensors, where D is the distance of the reference's OWN fp32 gradients from that fp64 evaluation (worst tensor).  On the tiny fixtures
     (batch seeds without ReLU ties, make_golden.relu_margin) D ~ 2e-6 and the bound is `tol` itself (1e-4 in fp32 mode); at
     DeiT-B size the reference's fp32 gradients are themselves only good to D ~ 5e-3 (tens of ReLU decisions within rounding of
     zero flip between fp32 and fp64), and no implementation can be closer to the reference than the reference is to itself.
@@ -187,11 +187,16 @@ def check_grad_samples(z, it, named_grads, tol, msgs, label='', rec=None, mtol=N
                        f'it{it}_grad_elem_p90': float(np.percentile(errs, 90)), f'it{it}_grad_elem_median': float(np.median(errs)),
                        f'it{it}_reference_fp32_vs_fp64_worst': D, f'it{it}_reference_fp32_vs_fp64_median': Dmed})
     bound, mbound = max(tol, 8 * D), max(tol / 10 if mtol is None else mtol, 4 * Dmed)
+    p90 = float(np.percentile(errs, 90))
     if tol >= 0.1:
-        p90 = float(np.percentile(errs, 90))
         if p90 > bound:
             msgs.append(f'{label}it{it} gradient elements, 90th percentile over tensors: {p90:.2e} (bound {bound:.1e})')
         bound = 3 * bound
+    elif p90 > max(tol, 3 * D):
+        # fp32 parity mode (round 4): nine tensors in ten are held to 3 D.  The single worst tensor keeps 8 D: at DeiT-B size it is
+        # always a BatchNorm bias behind a ReLU (full_pasa: auxiliary_head.0.up_convs.0.0.bn.bias at 6.4 D), where ONE activation
+        # decided the other way than in the reference's fp32 run moves the whole sum - the same event that makes up D itself.
+        msgs.append(f'{label}it{it} gradient elements, 90th percentile over tensors: {p90:.2e} (bound {max(tol, 3 * D):.1e})')
     if errs[w] > bound:
         msgs.append(f'{label}it{it} gradient elements of {keys[w]}: {errs[w]:.2e} of the tensor maximum (bound {bound:.1e}; the '
                     f"reference's own fp32 is {D:.1e} from its fp64 evaluation)")

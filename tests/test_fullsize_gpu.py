@@ -190,7 +190,7 @@ def _golden_run(name, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-@pytest.mark.parametrize('name', ['full_sup', 'full_pasa', 'full_768', 'full_ours', 'full_sup8', 'full_semi4'])
+@pytest.mark.parametrize('name', ['full_sup', 'full_pasa', 'full_768', 'full_ours', 'full_sup8', 'full_semi4', 'full_semi8_fwd'])
 def test_fullsize_step_vs_reference_golden(name, dtype, monkeypatch):
     import s4former_amd as S
     from tests import common as C
