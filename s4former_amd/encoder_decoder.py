@@ -24,9 +24,16 @@ from . import kernels as K
 from . import runtime
 from ._lib import S4FError
 from .base_module import BaseModule
-from .functional import LOGIT_LD, ZERO_POOL, join_side_streams, on_head_stream
+from .functional import LOGIT_LD, USE_SIDE_STREAM, ZERO_POOL, join_side_streams, on_head_stream, side_stream
 from .params import ParamStore
 from .registry import SEGMENTORS, build_backbone, build_head, build_neck
+
+# A/B switch (round 4): the EMA of everything behind the first EMA_SPLIT_LAYER teacher layers on the side stream, under the
+# teacher's first layers (update_ema_variables).  OFF by default: measured +0.4 ms per step on the default workload (29.31 ->
+# 29.74 ms, three interleaved pairs on one box, profiles/r04_ab_ema_overlap.txt) - the HBM-bound update (1.26 GB) takes the
+# bandwidth and the CUs the teacher's first GEMMs want; alone at the head of the step it costs 0.23 ms.
+EMA_OVERLAP = os.environ.get('S4F_EMA_OVERLAP', '0') != '0'
+EMA_SPLIT_LAYER = 2
 
 
 def add_prefix(inputs, prefix):
@@ -481,7 +488,48 @@ class EncoderDecoder(BaseSegmentor):
         arenas; the per-module signature of the reference is accepted and ignored."""
         s, t = self._student_store, self._teacher_store
         m = self.momentum_backbone if momentum is None else momentum
-        K.ema(t.flat, s.flat, t.flat_t, t.total, m, t.dtype)
+        cut = self._ema_split()
+        if not cut:
+            K.ema(t.flat, s.flat, t.flat_t, t.total, m, t.dtype)
+            return
+        # Round 4 (S4F_EMA_OVERLAP=1): only the head of the arena (embeddings + the first EMA_SPLIT_LAYER encoder layers, 17 % of
+        # DeiT-B) is updated in front of the teacher pass; the rest goes to the side stream and the teacher backbone waits for it
+        # in front of layer EMA_SPLIT_LAYER (vit.py forward_rank1), ~0.8 ms of teacher kernels later.
+        # Same arithmetic, same place in the iteration as the reference (encoder_decoder.py:416-423); forward_train joins the
+        # side stream before it returns, so a reader on the caller's stream never sees a half-updated teacher.
+        K.ema(t.flat[:cut], s.flat[:cut], None if t.flat_t is None else t.flat_t[:cut], cut, m, t.dtype)
+        cur, side = torch.cuda.current_stream(), side_stream(t.flat.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            K.ema(t.flat[cut:], s.flat[cut:], None if t.flat_t is None else t.flat_t[cut:], t.total - cut, m, t.dtype)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self.backbone_ema._pre_layer_wait = (EMA_SPLIT_LAYER, ev)
+
+    def _ema_split(self):
+        """arena offset where the side-stream part of the EMA starts (0 = one launch on the caller's stream)"""
+        t = self._teacher_store
+        key = (getattr(t, 'generation', 0), id(t.flat))
+        c = self.__dict__.get('_ema_cut')
+        if c is not None and c[0] == key:
+            return c[1]
+        cut = 0
+        if EMA_OVERLAP and USE_SIDE_STREAM and os.environ.get('S4F_TEACHER_GRAPH', '0') != '1' and t.flat.is_cuda:
+            import re
+            first = None
+            for e in t.entries:                              # arena order
+                mm = re.search(r'^backbone_ema\.layers\.(\d+)\.', e.name)
+                late = e.group != 'backbone' or (mm is not None and int(mm.group(1)) >= EMA_SPLIT_LAYER)
+                if late and first is None:
+                    first = e.off
+                if not late and first is not None:           # something the first layers need lies behind the cut: no split
+                    first = 0
+                    break
+            cut = first or 0
+            if len(self.backbone_ema.layers) <= EMA_SPLIT_LAYER:
+                cut = 0
+        self._ema_cut = (key, cut)
+        return cut
 
     def set_eval(self, ema=False):
         mods = [self.backbone_ema, self.decode_head_ema] if ema else [self.backbone, self.decode_head] + self._aux_list()

@@ -303,7 +303,10 @@ class VisionTransformer(BaseModule):
         pe = self.patch_embed.projection
         tokens = PatchEmbedFn.apply(x, pe.weight, pe.bias, self.cls_token, self.pos_embed, store)
         outs = []
-        for i, layer in enumerate(self.layers):
+        wait = self.__dict__.pop('_pre_layer_wait', None)   # (layer index, event): the part of this (teacher) model's weights that
+        for i, layer in enumerate(self.layers):             # the EMA updates on the side stream (encoder_decoder.update_ema_variables)
+            if wait is not None and i == wait[0]:
+                torch.cuda.current_stream().wait_event(wait[1])
             tokens = layer(tokens, mask)
             if i in self.out_indices:
                 outs.append(self.tap_view(tokens, hw_shape))

@@ -467,3 +467,46 @@ def test_teacher_hipgraph_matches_the_eager_teacher(dtype, monkeypatch):
     model.ensure_engine(torch.device('cuda', 0))
     b = both(meta['seed_b'] + 7)
     assert float((b - a).abs().max()) > 0.1 * float(a.abs().max()), 'the replay did not see the new weights'
+
+
+def test_ema_on_the_side_stream_gives_the_same_teacher(monkeypatch):
+    """round 4: the EMA of everything behind the first two teacher layers runs on the side stream under the teacher's first
+    layers (EncoderDecoder.update_ema_variables); the teacher backbone waits for it in front of layer 2.  The same update of
+    the same arenas, split over two streams: the teacher arena must come out BITWISE equal to the single launch, and so must
+    the logits and pseudo-labels of a teacher pass started right behind it with no synchronisation in between (fp32 mode)."""
+    from s4former_amd import encoder_decoder as ED
+    z, meta = load_gold('mt_pasa')
+    model, opt, sched = build_product(meta, 'fp32')
+    monkeypatch.setattr(ED, 'EMA_OVERLAP', True)
+    run_product(model, opt, sched, meta, iters=2)
+    assert model.backbone_ema.__dict__.get('_pre_layer_wait') is None, 'the teacher pass did not take the event'
+    t = model.teacher_store
+    cut = model._ema_split()
+    assert 0 < cut < t.group_ranges['backbone']['all'][1], cut
+    flat0 = t.flat.clone()
+    n0 = meta['n_sup'] + meta['n_unsup']
+    imgs, gt, metas = C.make_batch(meta['seed_b'] + 5, meta['n_sup'], meta['n_unsup'])
+    timg = imgs[n0:].cuda()
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(ED, 'EMA_OVERLAP', on)
+        model.__dict__.pop('_ema_cut', None)
+        t.flat.copy_(flat0)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            model.update_ema_variables(momentum=0.5)      # a large step: a teacher layer that read its weights too early would show
+            assert (model.backbone_ema.__dict__.get('_pre_layer_wait') is not None) == on
+            model.decode_head_ema._eval_override = True
+            try:
+                info = model.extract_teacher_info_ema(timg, metas[n0:])
+            finally:
+                model.decode_head_ema._eval_override = False
+        from s4former_amd.functional import join_side_streams
+        join_side_streams()
+        torch.cuda.synchronize()
+        res[on] = (t.flat.clone(), info['hard_seg_label'].clone(), info['seg_logits_lowres'].float().clone())
+    assert not torch.equal(res[True][0], flat0), 'the EMA did nothing'
+    assert torch.equal(res[True][0], res[False][0])
+    # fp32 parity mode: the teacher pass has no atomics - equal weights give equal logits, bit for bit
+    assert torch.equal(res[True][2], res[False][2]), float((res[True][2] - res[False][2]).abs().max())
+    assert torch.equal(res[True][1], res[False][1])
