@@ -690,8 +690,9 @@ class EncoderDecoder(BaseSegmentor):
             row_flag = torch.ones(nb, N, device=imgs.device)
             row_flag[ns:ns + nu] = flag
         outs = self.backbone.forward_rank1(imgs, (bias_u, row_flag, w))
-        f_sup = self.backbone.split_taps(outs, 0, ns)
-        f_mask = self.backbone.split_taps(outs, ns, ns + nu)
+        parts = self.backbone.split_taps_multi(outs, [(0, ns), (ns, ns + nu)] + ([(ns + nu, ns + 2 * nu)] if self.attn_mask_seperate_head else []))
+        f_sup, f_mask = parts[0], parts[1]
+        f_plain = parts[2] if self.attn_mask_seperate_head else None
         if self._decode_lockstep() and aug is None and not self.negative_class_ranking:
             # N > 1: the decode head's calls (labelled, masked pseudo-labelled, plain pseudo-labelled) advance layer by layer
             # TOGETHER: one SyncBN exchange per layer for all of them; BN running statistics are updated in call order
@@ -700,7 +701,7 @@ class EncoderDecoder(BaseSegmentor):
             calls = [(dh, f_sup, dh._loss_labels(sup['img_metas'], sup['gt_semantic_seg']), dh.loss_decode.loss_weight),
                      (dh, f_mask, pseudo, 1.0)]
             if self.attn_mask_seperate_head:
-                calls.append((dh, self.backbone.split_taps(outs, ns + nu, ns + 2 * nu), pseudo, 1.0))
+                calls.append((dh, f_plain, pseudo, 1.0))
             with on_head_stream(simg.device, 'decode'):
                 dl = type(dh).fused_losses_lockstep(calls)
                 loss_decode_sup = add_prefix({dh.loss_decode.loss_name: dl[0]}, 'decode')
@@ -715,7 +716,7 @@ class EncoderDecoder(BaseSegmentor):
                 self.losses.update(self._auxiliary_head_forward_train(f_sup, sup['img_metas'], sup['gt_semantic_seg']))
             self.losses.update(loss_decode_sup)
         else:
-            self._fused_heads_sequential(sup, stu, simg, outs, f_sup, f_mask, ns, nu, teacher_info, aug)
+            self._fused_heads_sequential(sup, stu, simg, f_plain, f_sup, f_mask, ns, nu, teacher_info, aug)
             return
         if self.iter_unsup_start != 0:
             if self.current_iter > self.iter_unsup_start:
@@ -723,7 +724,7 @@ class EncoderDecoder(BaseSegmentor):
         else:
             self.losses.update(unsup_loss)
 
-    def _fused_heads_sequential(self, sup, stu, simg, outs, f_sup, f_mask, ns, nu, teacher_info, aug=None):
+    def _fused_heads_sequential(self, sup, stu, simg, f_plain, f_sup, f_mask, ns, nu, teacher_info, aug=None):
         # supervised heads
         loss_decode_sup = self._decode_head_forward_train(f_sup, sup['img_metas'], sup['gt_semantic_seg'])
         if self.with_auxiliary_head:
@@ -739,7 +740,7 @@ class EncoderDecoder(BaseSegmentor):
             student_info = dict(img=simg, img_metas=stu['img_metas'], backbone_feature=f_mask)
             if self.attn_mask_seperate_head:
                 loss_unsup['loss_seg_unsup_attn_mask'] = self.compute_pseudo_loss(student_info, teacher_info)['loss_seg_unsup'] * 0.5
-                student_info['backbone_feature'] = self.backbone.split_taps(outs, ns + nu, ns + 2 * nu)
+                student_info['backbone_feature'] = f_plain
             losses = self.compute_pseudo_loss(student_info, teacher_info, aug=aug, ncr=self.negative_class_ranking)
             if self.negative_class_ranking:
                 loss_unsup['loss_ncr_unsup'] = losses['loss_ncr_unsup'] * 0.5

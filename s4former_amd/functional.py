@@ -40,6 +40,9 @@ USE_SIDE_STREAM = os.environ.get('S4F_SIDE_STREAM', '1') != '0'
 # A block of the 8-wave GEMMs holds a CU's whole register file (2 waves x 256 registers per SIMD): while the 216 blocks of the
 # grouped weight gradient are resident, the chain's kernels run on the 40 CUs that are left.
 LAYER_WG_SIDE = os.environ.get('S4F_LAYER_WG_SIDE', '1') != '0'
+# A/B switch (round 4): the image groups of a backbone tap share one gradient buffer written by the heads (TapSplitFn) instead
+# of autograd's slice / zero-fill / add plumbing
+TAP_SPLIT = os.environ.get('S4F_TAP_SPLIT', '1') != '0'
 _side = {}
 
 
@@ -875,12 +878,83 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
                    conv=(Bn, h, w, Cc, -1))
         del dy
     gh, gw = hp['grid']
-    dtok = torch.empty(Bn, ntok, E, device=dev, dtype=tokens.dtype)
-    dtok[:, 0].zero_()                               # the head drops the cls row: only it needs zeros, the rest is written below
+    td = getattr(tokens, '_s4f_tapdst', None)        # (holder, group): this call's rows of the tap's shared gradient buffer
+    acc = False
+    if td is not None and td[0].buf is not None:
+        dtok, acc = td[0].claim(td[1])
+    else:
+        td = None
+        dtok = torch.empty(Bn, ntok, E, device=dev, dtype=tokens.dtype)
+    if not acc:
+        dtok[:, 0].zero_()                           # the head drops the cls row: only it needs zeros, the rest is written below
     K.layernorm_bwd(dcur, tokens[:, 1:], sv['mean0'], sv['rstd0'], store.phys(hp['norm_w']), None, dtok[:, 1:], None,
                     store.grad_phys(hp['norm_w']), store.grad_phys(hp['norm_b']), Bn * gh * gw, E, code,
-                    rows_per_img=gh * gw, in_batch_stride=ntok * E)
-    return dtok
+                    rows_per_img=gh * gw, in_batch_stride=ntok * E, accumulate=acc)
+    if td is not None:
+        td[0].done(td[1])
+    return None if acc else dtok                     # accumulated into another call's rows: nothing for autograd to add
+
+
+class _TapGrad:
+    """The gradient of ONE backbone tap (token tensor [B, T+1, E]) that several head calls consume by image group
+    (labelled rows, pseudo-labelled rows, ...).  autograd's own plumbing for `tokens[a:b]` costs, per group and tap, a
+    full-size zero fill, a copy into the slice and full-size additions (about 30 ATen launches and 0.3 ms at the head of
+    the backbone's backward, profiles/r03_serial_launch_list.txt).  Here the heads' last backward kernel (the LayerNorm
+    backward) writes its rows of ONE buffer directly; a second head on the same rows (decode head and fourth auxiliary
+    head share the last tap) accumulates into them behind the first one's event and hands autograd no tensor at all."""
+
+    def __init__(self, tokens, bounds):
+        self.bounds = bounds
+        self.buf = torch.empty_like(tokens)      # (on the forward's stream; the heads' streams only write into it)
+        self.claims = {}                         # group index -> events of the writers so far
+
+    def claim(self, gi):
+        a, b = self.bounds[gi]
+        evs = self.claims.get(gi)
+        if evs is None:
+            self.claims[gi] = []
+            return self.buf[a:b], False
+        torch.cuda.current_stream().wait_event(evs[-1])
+        return self.buf[a:b], True
+
+    def done(self, gi):
+        ev = torch.cuda.Event()
+        ev.record()
+        self.claims[gi].append(ev)
+
+
+class TapSplitFn(Function):
+    """tokens [B, T+1, E] -> the views tokens[a:b] of the image groups; backward: see _TapGrad"""
+
+    @staticmethod
+    def forward(ctx, tokens, holder):
+        ctx.holder = holder
+        ctx.set_materialize_grads(False)
+        return tuple(tokens[a:b] for a, b in holder.bounds)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        h = ctx.holder
+        buf, cur = h.buf, torch.cuda.current_stream()
+        rows = set()
+        for gi, (a, b) in enumerate(h.bounds):
+            g, evs = grads[gi], h.claims.get(gi)
+            rows.update(range(a, b))
+            if evs is None:                      # no head wrote these rows in place
+                if g is None:
+                    buf[a:b].zero_()
+                else:
+                    buf[a:b].copy_(g)
+                continue
+            for ev in evs:
+                cur.wait_event(ev)
+            if g is not None and g.data_ptr() != buf[a:b].data_ptr():
+                buf[a:b].add_(g)                 # a consumer outside the protocol besides the heads
+        for i in range(buf.shape[0]):
+            if i not in rows:
+                buf[i].zero_()                   # images no group covers
+        h.buf = None
+        return buf, None
 
 
 HEAD_MARKS = None              # diagnostic (tools/exp/head_marks.py): list of (label, stream id, start event, end event, host t0, host t1)
@@ -965,7 +1039,7 @@ class HeadLossFn(Function):
         ctx.ncr_lo = None
         dtok = head_backward(dlo, dlo_t if dlo_t is not None else dlo, sv, hp, store)
         _mark_end(mk)
-        if ctx.consumer is not None:
+        if ctx.consumer is not None and dtok is not None:
             dtok.record_stream(ctx.consumer)          # allocated on the head's stream, read by the backbone's
         ctx.sv = None
         store.node_done()
@@ -1035,7 +1109,7 @@ class MultiHeadLossFn(Function):
         ex = _Exchange(n, world)
         dtoks = _drive([_head_backward_gen(a, b, sv, hp, store, ex) for a, b, sv, hp in gens], ex)
         for i in range(n):
-            if ctx.consumer is not None:
+            if ctx.consumer is not None and dtoks[i] is not None:
                 dtoks[i].record_stream(ctx.consumer)
             store.node_done()
             store.range_release(ctx.saved[i]['range'])

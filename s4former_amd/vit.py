@@ -332,6 +332,25 @@ class VisionTransformer(BaseModule):
             res.append(self.tap_view(t, o._s4f_grid))
         return tuple(res)
 
+    def split_taps_multi(self, outs, bounds):
+        """taps of several image groups [a, b) of a multi-group pass at once: list (per group) of tap tuples.  With gradients
+        the groups of a tap share ONE gradient buffer that the heads write directly (functional.TapSplitFn)."""
+        from .functional import TAP_SPLIT, TapSplitFn, _TapGrad
+        bounds = [(int(a), int(b)) for a, b in bounds]
+        res = [[] for _ in bounds]
+        for o in outs:
+            tok = o._s4f_tokens
+            if TAP_SPLIT and tok.requires_grad and torch.is_grad_enabled() and tok.is_cuda:
+                holder = _TapGrad(tok, bounds)
+                parts = TapSplitFn.apply(tok, holder)
+                for gi, t in enumerate(parts):
+                    t._s4f_tapdst = (holder, gi)
+            else:
+                parts = [tok[a:b] for a, b in bounds]
+            for gi, t in enumerate(parts):
+                res[gi].append(self.tap_view(t, o._s4f_grid))
+        return [tuple(r) for r in res]
+
     def train(self, mode=True):
         super().train(mode)
         return self
