@@ -330,6 +330,12 @@ def main():
                         algorithmic_gflop_per_launch=round(gemm_gflop / gemm_calls, 2),
                         launches_per_step=gemm_calls, avg_launch_ms=round(gemm_ms / gemm_calls, 4),
                         share_of_step_kernel_time=round(gemm_ms / total_ms, 3),
+                        # which launch path the per-GEMM durations were taken on: one extra step AFTER the timed windows with
+                        # an event pair around every C-ABI launch - the encoder layers therefore on their per-kernel path
+                        # (LayerFn), not behind s4f_encoder_layer_fwd / _bwd as in the timed steps (same kernels, same streams;
+                        # tests/test_step_gpu.py::test_launch_paths_of_the_encoder_layer_agree holds the two paths together)
+                        launch_path='per-kernel C-ABI launches under _lib.CallProfiler (one profiled step after the timed windows); '
+                                    'the timed steps issue each encoder layer through s4f_encoder_layer_fwd / _bwd',
                         step=dict(achieved=round(step_tflops, 1), frac=round(step_tflops / peak, 4),
                                   gflop_per_step_per_gpu=round(gflop_step, 1)))
 

@@ -85,9 +85,9 @@ typedef struct s4f_gemm_desc {
   int32_t tile_hint;        /* kernel selection, see below (here: fills the alignment hole in front of `pos`) */
   const float* pos;         /* fp32 [pos_period, N] or NULL */
   /* tile_hint: 0 = automatic; 1 = 128x128 register-staged kernel; 2 = 256x128 LDS-DMA kernel;
-   * 3 = 256x256 LDS-DMA kernel, 8 waves; 4 = 256x256, 16 waves; 5 = 256x256, 16 waves, K step 32, 4-stage ring
-   * with counted waits; 6 = 8 waves, K step 32; 7 = 4 waves (AGPR accumulators); 8 / 9 = 256x192 tile, 16 / 8 waves
-   * (row-major A with row- or k-major B only: N = 768 / 2304 of the token GEMMs).  2-9: bf16 only.  In the kernels of
+   * 3 = 256x256 LDS-DMA kernel, 8 waves; 4 = 256x256, 16 waves; 5 - 7 = round-1 experiments, removed (treated as 0);
+   * 8 / 9 = 256x192 tile, 16 / 8 waves (row-major A with row- or k-major B only: N = 768 / 2304 of the token GEMMs);
+   * 10 = 256x256, 8 waves in a ping-pong schedule (gemm5 / gemm6).  2-10: bf16 only.  In the kernels of
    * hints 3, 4, 8, 9 a row remainder M % 256 of at most 16 rows (one cls row per image) is folded into the last tile row. */
   /* optional fp32 [N]: += column sums of the T output as stored (after the activation) - the bias gradient of the linear
    * layer whose input gradient this GEMM produces (vit.py:99-127), taken from the output tile while it is staged instead of
