@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void main_kernel(const Args a) {
   uint32_t* const Ubp = reinterpret_cast<uint32_t*>(smem + NSTAGE * LDS_STAGE);
   int* const redo = reinterpret_cast<int*>(smem + LDS_TOTAL - 64);
   if (tid == 0) *redo = 0;
-  if (HAS_BIAS) {
+  if (HAS_BIAS && !(FF_ABL & 16)) {
     constexpr int NU = (MAXN + 64 + 255) / 256;
     float ux[NU];
 #pragma unroll
@@ -245,7 +245,8 @@ __global__ __launch_bounds__(256, 1) void main_kernel(const Args a) {
     for (int r = 0; r < 16; ++r) cst[qt][r] = 0.f;
 
 #ifndef FF_ABL
-#define FF_ABL 0                                         // timing experiments only (results are wrong): 1 no stage barrier, 2 no refill
+#define FF_ABL 0                                         // timing experiments only (results are wrong): 1 no stage barrier, 2 no refill,
+                                                          // 4 no bias product (5th contraction step), 8 no bias fragment reads, 16 no bias prologue
 #endif
 #define FF_SB() __builtin_amdgcn_sched_barrier(0)
 #ifdef FF_STAMPS
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256, 1) void main_kernel(const Args a) {
       constexpr int ks = decltype(KS)::value;
       if constexpr (ks == 0) st[0] = mma32(kfr[0], qf[0][0], cst[0]);
       else if constexpr (ks < 4) st[0] = mma32(kfr[ks], qf[0][ks], st[0]);
-      else st[0] = mma32(as_bf16x8(kx), qx[0], st[0]);
+      else if constexpr (!(FF_ABL & 4)) st[0] = mma32(as_bf16x8(kx), qx[0], st[0]);
       FF_SB();
       if constexpr (ks < 4) {
         if constexpr (!first) soft2(I1{}, std::integral_constant<int, 6 + 2 * ks>{});
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void main_kernel(const Args a) {
       constexpr int ks = decltype(KS)::value;
       if constexpr (ks == 0) st[1] = mma32(kfr[0], qf[1][0], cst[1]);
       else if constexpr (ks < 4) st[1] = mma32(kfr[ks], qf[1][ks], st[1]);
-      else st[1] = mma32(as_bf16x8(kx), qx[1], st[1]);
+      else if constexpr (!(FF_ABL & 4)) st[1] = mma32(as_bf16x8(kx), qx[1], st[1]);
       FF_SB();
       if constexpr (ks < 4) {
         soft2(I0{}, std::integral_constant<int, 6 + 2 * ks>{});
@@ -383,8 +384,8 @@ __global__ __launch_bounds__(256, 1) void main_kernel(const Args a) {
       else soft2(I1{}, std::integral_constant<int, 2 * (g - 1)>{});
       if constexpr (!last) {
         if constexpr (g >= 2) read_k(std::integral_constant<int, g - 2>{}, t + 1);
-        if constexpr (HAS_BIAS && g == 0) kxn = read_kx(t + 1);
-        if constexpr (HAS_BIAS && g == 3) { kx[0] = kxn; kx[1] = kxn; }
+        if constexpr (HAS_BIAS && g == 0 && !(FF_ABL & 8)) kxn = read_kx(t + 1);
+        if constexpr (HAS_BIAS && g == 3 && !(FF_ABL & 8)) { kx[0] = kxn; kx[1] = kxn; }
       }
       FF_SB();
     });
