@@ -18,6 +18,10 @@
 //     vector port, not by whole softmax blocks that leave the matrix pipe idle.
 //   * N = 1 + 16 k: the odd query is not given a fifth, almost empty block; it is a matrix-vector side kernel.
 #include "common.h"
+#ifndef FF_ABL
+#define FF_ABL 0                                         // timing experiments only (results are wrong): 1 no stage barrier, 2 no refill,
+                                                          // 4 no bias product (5th contraction step), 8 no bias fragment reads, 16 no bias prologue
+#endif
 #include "../../include/s4f.h"
 
 namespace {
@@ -244,10 +248,6 @@ __global__ __launch_bounds__(256, 1) void main_kernel(const Args a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) cst[qt][r] = 0.f;
 
-#ifndef FF_ABL
-#define FF_ABL 0                                         // timing experiments only (results are wrong): 1 no stage barrier, 2 no refill,
-                                                          // 4 no bias product (5th contraction step), 8 no bias fragment reads, 16 no bias prologue
-#endif
 #define FF_SB() __builtin_amdgcn_sched_barrier(0)
 #ifdef FF_STAMPS
   unsigned long long tst[5], tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = 0;
