@@ -689,8 +689,9 @@ class EncoderDecoder(BaseSegmentor):
         if flag is not None:
             row_flag = torch.ones(nb, N, device=imgs.device)
             row_flag[ns:ns + nu] = flag
-        outs = self.backbone.forward_rank1(imgs, (bias_u, row_flag, w))
-        parts = self.backbone.split_taps_multi(outs, [(0, ns), (ns, ns + nu)] + ([(ns + nu, ns + 2 * nu)] if self.attn_mask_seperate_head else []))
+        bounds = tuple([(0, ns), (ns, ns + nu)] + ([(ns + nu, ns + 2 * nu)] if self.attn_mask_seperate_head else []))
+        outs = self.backbone.forward_rank1(imgs, (bias_u, row_flag, w), tap_groups=bounds)
+        parts = self.backbone.split_taps_multi(outs, bounds)
         f_sup, f_mask = parts[0], parts[1]
         f_plain = parts[2] if self.attn_mask_seperate_head else None
         if self._decode_lockstep() and aug is None and not self.negative_class_ranking:

@@ -924,37 +924,64 @@ class _TapGrad:
 
 
 class TapSplitFn(Function):
-    """tokens [B, T+1, E] -> the views tokens[a:b] of the image groups; backward: see _TapGrad"""
+    """tokens [B, T+1, E] -> (tokens for the next encoder layer if `chain`,) + the views tokens[a:b] of the image groups;
+    backward: see _TapGrad.  With the chain output the tap's gradient is added IN PLACE into the rows of the chain's gradient
+    that some head covers (rows without a head get nothing: no zero fill, no full-size addition by autograd)."""
 
     @staticmethod
-    def forward(ctx, tokens, holder):
-        ctx.holder = holder
+    def forward(ctx, tokens, holder, chain):
+        ctx.holder, ctx.chain = holder, chain
         ctx.set_materialize_grads(False)
-        return tuple(tokens[a:b] for a, b in holder.bounds)
+        parts = tuple(tokens[a:b] for a, b in holder.bounds)
+        return ((tokens.view_as(tokens),) + parts) if chain else parts
 
     @staticmethod
     def backward(ctx, *grads):
         h = ctx.holder
         buf, cur = h.buf, torch.cuda.current_stream()
+        dchain = None
+        if ctx.chain:
+            dchain, grads = grads[0], grads[1:]
         rows = set()
+        ready = []                                   # groups whose rows of buf are complete
         for gi, (a, b) in enumerate(h.bounds):
             g, evs = grads[gi], h.claims.get(gi)
-            rows.update(range(a, b))
-            if evs is None:                      # no head wrote these rows in place
+            if evs is None:                          # no head wrote these rows in place
                 if g is None:
-                    buf[a:b].zero_()
-                else:
-                    buf[a:b].copy_(g)
-                continue
-            for ev in evs:
-                cur.wait_event(ev)
-            if g is not None and g.data_ptr() != buf[a:b].data_ptr():
-                buf[a:b].add_(g)                 # a consumer outside the protocol besides the heads
+                    continue
+                buf[a:b].copy_(g)
+            else:
+                for ev in evs:
+                    cur.wait_event(ev)
+                if g is not None and g.data_ptr() != buf[a:b].data_ptr():
+                    buf[a:b].add_(g)                 # a consumer outside the protocol besides the heads
+            rows.update(range(a, b))
+            ready.append((a, b))
+        h.buf = None
+        if dchain is not None:
+            if dchain.dtype != buf.dtype:
+                raise S4FError('tap gradient and chain gradient differ in type')
+            if buf.dtype == torch.float32 and dchain.is_contiguous():
+                # the layer behind this tap left the operand-typed copy and the column sums of its gradient ON the tensor
+                # (LayerFn.backward: _s4f_t, _s4f_colsum, valid for the tensor's version): the copy is kept in step by the same
+                # pass, the column sums are dropped (the layer in front then sums the columns itself, as it did when autograd's
+                # addition handed it a fresh tensor).  Raw-pointer writes do not move the version counter.
+                tt = getattr(dchain, '_s4f_t', None)
+                g0t = tt[0] if tt is not None and tt[1] == dchain._version and tt[2] == dchain.data_ptr() else None
+                for a, b in ready:                   # (groups do not overlap)
+                    K.add_f32(dchain[a:b], buf[a:b], dchain[a:b], None if g0t is None else g0t[a:b], F32 if g0t is None else BF16)
+                if ready:
+                    dchain._s4f_colsum = None
+                    if g0t is None:
+                        dchain._s4f_t = None
+            else:
+                for a, b in ready:
+                    dchain[a:b].add_(buf[a:b])       # (moves the version counter: what the layer left on the tensor lapses)
+            return dchain, None, None
         for i in range(buf.shape[0]):
             if i not in rows:
-                buf[i].zero_()                   # images no group covers
-        h.buf = None
-        return buf, None
+                buf[i].zero_()                       # images no group covers
+        return buf, None, None
 
 
 HEAD_MARKS = None              # diagnostic (tools/exp/head_marks.py): list of (label, stream id, start event, end event, host t0, host t1)

@@ -290,7 +290,7 @@ class VisionTransformer(BaseModule):
             mask = self._rank1_mask(attn_mask, attn_mask_weight, adaptive_attn_mask)
         return self.forward_rank1(inputs, mask)
 
-    def forward_rank1(self, inputs, mask=None):
+    def forward_rank1(self, inputs, mask=None, tap_groups=None):
         """forward with the PASA mask already in rank-1 form (bias_u [B,N], row_flag [B,N] | None, weight) | None.
         The segmentor uses this to push several image groups (supervised, masked / plain unlabeled) through the
         backbone in ONE pass: every backbone op is per image, rows of images without a mask carry u = 0."""
@@ -309,7 +309,13 @@ class VisionTransformer(BaseModule):
                 torch.cuda.current_stream().wait_event(wait[1])
             tokens = layer(tokens, mask)
             if i in self.out_indices:
-                outs.append(self.tap_view(tokens, hw_shape))
+                parts = None
+                if tap_groups is not None:
+                    tokens, parts = self._split_tap(tokens, tap_groups, chain=i + 1 < len(self.layers))
+                o = self.tap_view(tokens, hw_shape)
+                if parts is not None:
+                    (o[0] if isinstance(o, list) else o)._s4f_parts = (tuple(tap_groups), parts)
+                outs.append(o)
         self.multi_self_attn = [[], hw_shape]
         return tuple(outs)
 
@@ -332,23 +338,36 @@ class VisionTransformer(BaseModule):
             res.append(self.tap_view(t, o._s4f_grid))
         return tuple(res)
 
+    @staticmethod
+    def _split_tap(tok, bounds, chain):
+        """(tokens for the chain, group views) of one tap; None for the views when the shared-gradient node does not apply"""
+        from .functional import TAP_SPLIT, TapSplitFn, _TapGrad
+        if not (TAP_SPLIT and tok.requires_grad and torch.is_grad_enabled() and tok.is_cuda):
+            return tok, None
+        holder = _TapGrad(tok, bounds)
+        res = TapSplitFn.apply(tok, holder, chain)
+        nxt, parts = (res[0], res[1:]) if chain else (tok, res)
+        for gi, t in enumerate(parts):
+            t._s4f_tapdst = (holder, gi)
+        return nxt, parts
+
     def split_taps_multi(self, outs, bounds):
         """taps of several image groups [a, b) of a multi-group pass at once: list (per group) of tap tuples.  With gradients
-        the groups of a tap share ONE gradient buffer that the heads write directly (functional.TapSplitFn)."""
-        from .functional import TAP_SPLIT, TapSplitFn, _TapGrad
-        bounds = [(int(a), int(b)) for a, b in bounds]
+        the groups of a tap share ONE gradient buffer that the heads write directly (functional.TapSplitFn); a pass that was
+        given `tap_groups` has made the split where the tap leaves the chain (forward_rank1)."""
+        bounds = tuple((int(a), int(b)) for a, b in bounds)
         res = [[] for _ in bounds]
         for o in outs:
-            tok = o._s4f_tokens
-            if TAP_SPLIT and tok.requires_grad and torch.is_grad_enabled() and tok.is_cuda:
-                holder = _TapGrad(tok, bounds)
-                parts = TapSplitFn.apply(tok, holder)
-                for gi, t in enumerate(parts):
-                    t._s4f_tapdst = (holder, gi)
+            o0 = o[0] if isinstance(o, list) else o
+            pre = getattr(o0, '_s4f_parts', None)
+            if pre is not None and pre[0] == bounds:
+                parts = pre[1]
             else:
-                parts = [tok[a:b] for a, b in bounds]
+                _, parts = self._split_tap(o0._s4f_tokens, bounds, chain=False)
+                if parts is None:
+                    parts = [o0._s4f_tokens[a:b] for a, b in bounds]
             for gi, t in enumerate(parts):
-                res[gi].append(self.tap_view(t, o._s4f_grid))
+                res[gi].append(self.tap_view(t, o0._s4f_grid))
         return [tuple(r) for r in res]
 
     def train(self, mode=True):
