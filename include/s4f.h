@@ -320,6 +320,12 @@ int s4f_mix_images(const float* img, float* out, const int* box, const int* perm
                    s4f_stream stream);
 /* the same CutMix on the uint8 pseudo-labels [B, H, W] (labels are not shuffled) */
 int s4f_cutmix_labels(const uint8_t* labels, uint8_t* out, const int* box, int B, int H, int W, s4f_stream stream);
+/* Round 4: the PASA patch un-confidence (encoder_decoder.py:547-555: per-patch mean of 1 - conf_mask) written straight into the
+ * rank-1 bias layout that s4f_attention_fwd / s4f_encoder_layer_fwd read (vit.py:519-535): out fp32 [rows_total, 1 + (H/ps)(W/ps)],
+ * zero except rows [row0, row0 + B) (the images of the pass that carry a mask), column 0 (cls) = 0, column 1 + p = mean over the
+ * ps x ps pixels of patch p of (1 - conf).  conf u8 [B, H, W] with 0 / non-zero entries (s4f_up_pseudo_label's conf output).
+ * Replaces a cast, a subtraction, a reduction, a division, a cat, a zero fill and a slice copy of the reference's torch path. */
+int s4f_pasa_patch_u(const uint8_t* conf, float* out, int B, int H, int W, int ps, int rows_total, int row0, s4f_stream stream);
 /* out[r, :] = src[map[r], :]  (rows of C values of type X): the token un-shuffle of decode_head.py:186-212 and its adjoint */
 int s4f_gather_rows(const void* src, void* out, const int* map, int64_t rows, int C, int xdtype, s4f_stream stream);
 

@@ -104,6 +104,7 @@ _SIGS = {
     's4f_mix_images': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     's4f_cutmix_labels': [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     's4f_gather_rows': [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p],
+    's4f_pasa_patch_u': [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     's4f_resize_bilinear_nchw': [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_int, c_int, c_void_p],
     's4f_softmax_argmax_nchw': [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     's4f_confusion_counts': [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p],

@@ -638,6 +638,36 @@ S4F_API int s4f_gather_rows(const void* src, void* out, const int* map, int64_t 
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------- PASA bias rows
+// one thread per output element of the [rows_total, 1 + gh gw] bias matrix: rows of the images that carry a confidence map get
+// the per-patch mean of (1 - conf) (256 - count of confident pixels over ps x ps, exact in fp32), everything else 0
+__global__ __launch_bounds__(256) void pasa_patch_u_kernel(const uint8_t* __restrict__ conf, float* __restrict__ out, int B, int H, int W,
+                                                           int ps, int rows_total, int row0) {
+  const int gw = W / ps, np1 = (H / ps) * gw + 1;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)rows_total * np1) return;
+  const int row = (int)(i / np1), col = (int)(i - (long)row * np1);
+  float v = 0.f;
+  if (row >= row0 && row < row0 + B && col > 0) {
+    const int p = col - 1, py = p / gw, px = p - py * gw;
+    const uint8_t* c = conf + ((long)(row - row0) * H + (long)py * ps) * W + (long)px * ps;
+    int cnt = 0;
+    for (int y = 0; y < ps; ++y)
+      for (int x = 0; x < ps; ++x) cnt += c[(long)y * W + x] != 0 ? 1 : 0;
+    v = (float)(ps * ps - cnt) / (float)(ps * ps);
+  }
+  out[i] = v;
+}
+
+S4F_API int s4f_pasa_patch_u(const uint8_t* conf, float* out, int B, int H, int W, int ps, int rows_total, int row0, s4f_stream stream) {
+  S4F_CHECK(conf && out && B > 0 && H > 0 && W > 0 && ps > 0 && H % ps == 0 && W % ps == 0, "s4f_pasa_patch_u: bad shape");
+  S4F_CHECK(row0 >= 0 && row0 + B <= rows_total, "s4f_pasa_patch_u: rows [row0, row0 + B) outside the output");
+  const long n = (long)rows_total * ((long)(H / ps) * (W / ps) + 1);
+  hipLaunchKernelGGL(pasa_patch_u_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, conf, out, B, H, W, ps, rows_total, row0);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
 S4F_API int s4f_add_f32(const float* a, const float* b, float* out, void* out_t, int64_t n, int dtype, s4f_stream stream) {
   DT_CHECK("s4f_add_f32");
   S4F_CHECK(a && b && out && n > 0 && n % 4 == 0, "s4f_add_f32: bad args (n must be a multiple of 4)");

@@ -667,8 +667,12 @@ class EncoderDecoder(BaseSegmentor):
         teacher_info = self._teacher_pass(data_groups['unsup_teacher'], stu)
         sup_imgs, simg = sup['img'], stu['img']
         ns, nu = sup_imgs.shape[0], simg.shape[0]
-        u = self._conf_to_patch_u(teacher_info['conf_mask'])
-        bu, flag, w = self.backbone._rank1_mask(u, self.attn_mask_weight, self.adaptive_attn_mask)
+        conf = teacher_info['conf_mask']
+        direct = (not self.adaptive_attn_mask and conf.dtype == torch.uint8 and conf.is_contiguous() and self.backbone.with_cls_token
+                  and conf.shape[1] % self.patchsize == 0 and conf.shape[2] % self.patchsize == 0)
+        if not direct:
+            u = self._conf_to_patch_u(conf)
+            bu, flag, w = self.backbone._rank1_mask(u, self.attn_mask_weight, self.adaptive_attn_mask)
         plain_img, aug = simg, None
         if self.attn_mask_seperate_head and self.use_PatchShuffle_w_Cutmix:
             plain_img, aug = self._strong_augment(simg, teacher_info)       # images of the plain pass, labels, token maps
@@ -682,13 +686,20 @@ class EncoderDecoder(BaseSegmentor):
             imgs = base[off:off + nb]
         else:
             imgs = torch.cat(groups, 0)
-        N = bu.shape[1]
-        bias_u = torch.zeros(nb, N, device=imgs.device)
-        bias_u[ns:ns + nu] = bu
         row_flag = None
-        if flag is not None:
-            row_flag = torch.ones(nb, N, device=imgs.device)
-            row_flag[ns:ns + nu] = flag
+        if direct:
+            # one launch writes the whole bias matrix (zero rows for the images without a mask): s4f_pasa_patch_u
+            ps = self.patchsize
+            bias_u = torch.empty(nb, (conf.shape[1] // ps) * (conf.shape[2] // ps) + 1, device=imgs.device)
+            K.pasa_patch_u(conf, bias_u, ps, ns)
+            w = float(self.attn_mask_weight)
+        else:
+            N = bu.shape[1]
+            bias_u = torch.zeros(nb, N, device=imgs.device)
+            bias_u[ns:ns + nu] = bu
+            if flag is not None:
+                row_flag = torch.ones(nb, N, device=imgs.device)
+                row_flag[ns:ns + nu] = flag
         bounds = tuple([(0, ns), (ns, ns + nu)] + ([(ns + nu, ns + 2 * nu)] if self.attn_mask_seperate_head else []))
         outs = self.backbone.forward_rank1(imgs, (bias_u, row_flag, w), tap_groups=bounds)
         parts = self.backbone.split_taps_multi(outs, bounds)

@@ -15,7 +15,7 @@ __all__ = ['gemm', 'wgrad_grouped', 'transpose_many', 'cast', 'cast_back', 'im2c
            'layernorm_bwd', 'add_f32', 'attention_fwd', 'attention_bwd', 'attention_bwd_fused', 'attention_bwd_ws_bytes', 'bn_stats', 'bn_finalize',
            'bn_relu_up_fwd', 'bn_relu_up_bwd', 'bn_bwd_apply', 'bn_param_grads', 'upce_fwd', 'upce_bwd',
            'up_pseudo_label', 'up_logits_nchw', 'ce_fwd', 'ce_bwd', 'ema', 'sgd_momentum', 'ncr_fwd', 'ncr_bwd', 'mix_images',
-           'cutmix_labels', 'gather_rows', 'resize_bilinear', 'softmax_argmax', 'confusion_counts']
+           'cutmix_labels', 'gather_rows', 'pasa_patch_u', 'resize_bilinear', 'softmax_argmax', 'confusion_counts']
 
 
 def _need(t, n, what):
@@ -662,6 +662,17 @@ def gather_rows(src, out, row_map, rows, C):
     if C % (8 if xd == BF16 else 4):
         raise S4FError('gather_rows: rows must be whole 16-byte chunks')
     call('s4f_gather_rows', p(src), p(out), p(row_map), rows, C, xd, stream())
+
+
+def pasa_patch_u(conf, out, ps, row0):
+    """out [rows_total, 1 + patches] fp32 := 0 except rows [row0, row0 + B): cls column 0, patch columns the mean of 1 - conf"""
+    if conf.dim() != 3 or out.dim() != 2:
+        raise S4FError('pasa_patch_u: conf [B, H, W] u8, out [rows, 1 + patches] fp32')
+    B, H, W = conf.shape
+    _chk_u8(conf, B * H * W, 'pasa_patch_u conf'); _chk_f32(out, 'pasa_patch_u out')
+    if H % ps or W % ps or out.shape[1] != (H // ps) * (W // ps) + 1 or not out.is_contiguous() or not conf.is_contiguous():
+        raise S4FError('pasa_patch_u: shapes do not match the patch grid')
+    call('s4f_pasa_patch_u', p(conf), p(out), B, H, W, ps, out.shape[0], row0, stream())
 
 
 def resize_bilinear(x, size, align_corners=False, window=None):

@@ -1078,3 +1078,21 @@ def test_patch_embed_bf16_tokens(K):
     out = torch.empty_like(src)
     K.gather_rows(src, out, perm, 40, 768)
     assert torch.equal(out.cpu(), src.cpu()[perm.cpu().long()]), 'bf16 row gather'
+
+
+@pytest.mark.parametrize('B,H,W,ps,rows,row0', [(2, 64, 64, 16, 5, 2), (1, 96, 32, 16, 1, 0), (3, 32, 48, 8, 3, 0)])
+def test_pasa_patch_u(K, B, H, W, ps, rows, row0):
+    """s4f_pasa_patch_u against the reference's arithmetic (encoder_decoder.py:547-555: conf.view(B, H/ps, ps, W/ps, ps), mean of
+    1 - conf over each patch) and vit.py:519-523's zero cls column, written into the rows of a multi-group pass: bit-exact
+    (counts over 64 or 256 pixels are exact in fp32); rows of images without a mask are zero; a bad row range is refused."""
+    g = torch.Generator().manual_seed(11)
+    conf = (torch.rand(B, H, W, generator=g) > 0.4).to(torch.uint8)
+    c = conf.view(B, H // ps, ps, W // ps, ps).to(torch.float32)
+    u = ((1.0 - c).sum(dim=(2, 4)) / (ps * ps)).reshape(B, -1)
+    ref = torch.zeros(rows, u.shape[1] + 1)
+    ref[row0:row0 + B, 1:] = u
+    out = torch.full((rows, u.shape[1] + 1), float('nan'), device='cuda')
+    K.pasa_patch_u(conf.cuda(), out, ps, row0)
+    assert torch.equal(out.cpu(), ref)
+    with pytest.raises(RuntimeError):
+        K.pasa_patch_u(conf.cuda(), out, ps, rows - B + 1)
