@@ -1,22 +1,26 @@
 // Attention forward (bf16 perf mode), head dim 64, round 4: the flash-style forward rebuilt on what the one-sweep backward
 // (attn_bwd.hip) measured about this chip's issue rules.  Replaces nn.MultiheadAttention's core inside mmcv's MultiheadAttention
-// (reference vit.py:99-103,113-121; PASA bias vit.py:519-535); attn_fwd2_kernel (attention.hip) stays as the fallback
-// (S4F_ATTN_FWD3=0) and the fp32 parity path is untouched.
+// (reference vit.py:99-103,113-121; PASA bias vit.py:519-535).  s4f_attention_fwd dispatches to it where it measured ahead of
+// attn_fwd2_kernel (attention.hip): no bias, grids that fill their last round of CUs (DESIGN A.15); s4f_attention_fwd_q256 calls it
+// directly.  The fp32 parity path is untouched.
 //
 //   * one workgroup = 4 waves = 256 queries of one (image, head), ONE wave per SIMD with up to 512 registers: a wave owns 64
-//     queries (two 32-query tiles) and keeps O^T (64 accumulator registers) and its scaled Q fragments for the whole sweep;
-//   * 32x32x16 MFMAs, S^T = K Q^T with the QUERY ON THE LANE: the running maximum is the MFMA's start accumulator (p = exp2 of
-//     the raw output), softmax statistics are lane-local, and the P accumulators are, as they stand, the B operand of
-//     O^T += V^T P^T;
-//   * K needs no LDS at all: its A-operand fragment of a lane is 16 contiguous bytes of one key row - plain global loads, one
-//     tile ahead; V crosses LDS once (two register-staged 16-byte chunks per thread and 64-key stage into the 8-row x 32-column
-//     subtile image, read back by ds_read_b64_tr_b16);
-//   * the sweep over 32-key tiles is an explicit software pipeline pinned with sched_barrier(0): per tile 16 MFMAs in the order
-//     S(t, q0) PV(t-1, q1) S(t, q1) PV(t, q0), and EVERY MFMA gap carries two scores' worth of softmax work (the row maximum of
-//     a finished tile in the first gap behind it) plus at most two LDS reads / one global load: a gap hides ~24 cycles of
-//     vector issue (tools/exp/ubench/mfma_valu.hip), the forward at head dim 64 has ~39 per gap, so the kernel is bound by the
-//     vector port, not by whole softmax blocks that leave the matrix pipe idle.
-//   * N = 1 + 16 k: the odd query is not given a fifth, almost empty block; it is a matrix-vector side kernel.
+//     queries (two 32-query tiles) and keeps O^T (64 accumulator registers, tied inline-asm MFMAs) and its scaled Q fragments
+//     (accumulator half too) for the whole sweep;
+//   * 32x32x16 MFMAs, S^T = K Q^T with the QUERY ON THE LANE: softmax statistics are lane-local and the P accumulators are, as
+//     they stand, the B operand of O^T += V^T P^T;
+//   * K and V stages (64 keys) both by inline-asm LDS-DMA two stages ahead into the 8-row x 32-column subtile image (row reads for
+//     the K fragments, ds_read_b64_tr_b16 for V^T); the kernel counts its own vmcnt - mixed with tracked loads hipcc over-waits;
+//   * the PASA bias w u[key] flag[query] is a FIFTH contraction step (K~ = [k, b_hi, b_lo, b_hi, b_lo], Q~ = [q, f_hi, f_hi, f_lo,
+//     f_lo], two bf16 each): no vector work at all;
+//   * NO running maximum: the reference point of a row's exponentials is the maximum of its first key tile (p may exceed 1; fp32
+//     sums and bf16 probabilities carry it to 2^100); a block whose row sums leave that range redoes its rows with an exact
+//     always-rescale sweep further down in the same kernel.  So the sweep over 32-key tiles is ONE basic block: an explicit
+//     software pipeline pinned with sched_barrier(0), per tile 16 (18) MFMAs in the order S(t, q0) PV(t-1, q1) S(t, q1) PV(t, q0)
+//     with one score pair (2 exp2, 2 adds, 1 pack) in every MFMA gap.  A gap hides ~20 cycles of vector issue
+//     (tools/exp/ubench/mfma_valu.hip) and the forward at head dim 64 has ~44 per gap: the kernel is bound by the vector port;
+//   * the last key tile (the only one that can be ragged) is peeled; N = 256 k + 1: the odd query is not given a fifth, almost
+//     empty block; it is a matrix-vector side kernel (folding it into the last block was measured and lost, DESIGN A.15).
 #include "common.h"
 #ifndef FF_ABL
 #define FF_ABL 0                                         // timing experiments only (results are wrong): 1 no stage barrier, 2 no refill,
