@@ -146,10 +146,10 @@ def setup_data_parallel(model, optimizer, device, reducer=None):
 
     N > 1 defaults: all-reduce of a span of the gradient arena during backward as soon as it is final (three encoder layers per
     bucket; a head group as soon as its last range has reported: ParamStore.range_done), the SGD of a span behind its
-    all-reduce, both on a communication stream of the reducer's own, and the heads advancing in lockstep
-    (S4F_AUX_LOCKSTEP / S4F_DECODE_LOCKSTEP = auto: one SyncBN exchange per head layer for all of them).  None of it has run
-    with a peer on hardware yet.  (Round 2 - 3 also bound the communication to the weight-gradient stream's
-    hardware queue by the streams' first-use order; its own self-check never passed on any box and the path was removed.)
+    all-reduce, both on a communication stream of the reducer's own, and the empirical first-use order of the package's streams
+    (S4F_STREAM_ORDER, below).  Opt-in: the heads advancing in lockstep (S4F_AUX_LOCKSTEP=1 / S4F_DECODE_LOCKSTEP=1: one SyncBN
+    exchange per head layer for all of them; slower through a one-rank RCCL group on the round-4 tree, unmeasured with peers).
+    None of it has run with a peer on hardware yet.
     Returns the reducer; per step:  backward -> join_side_streams() -> reducer.reduce_(store.grad) -> reducer.wait() ->
     optimizer.step(grad_scale=reducer.grad_scale())."""
     reducer = reducer if reducer is not None else GradReducer()
@@ -165,6 +165,16 @@ def setup_data_parallel(model, optimizer, device, reducer=None):
         # three encoder layers (3 x 7.09 M fp32 = 85 MB) per gradient bucket: 4 all-reduces for the backbone during backward
         # + the rest (heads, patch embedding) in 128 MB buckets at the end, instead of one collective per layer and head (41)
         model.student_store.coalesce_min = int(os.environ.get('S4F_BUCKET_MIN_ELEMS', str(20_000_000)))
+    if collectives_active() and os.environ.get('S4F_STREAM_ORDER', '1') != '0' and torch.device(device).type == 'cuda':
+        # First-use order of the package's streams (the runtime binds a stream to one of its four hardware queues at its first
+        # use; two streams on one queue serialise): RCCL's stream (used by the broadcasts above), decode, aux, two throw-away
+        # streams, weight gradients.  An EMPIRICAL setting, kept for what it measures through a one-rank RCCL group
+        # (tools/exp/rccl_ab3.sh): 31.7 -> 29.9 ms per step on one box (28.7 ms without a process group; round 2: 33.95 -> 32.58).
+        # Round 3 wrapped it in a model of the queue pattern with a self-check that never passed; round 4 first deleted both and
+        # lost 2 ms at N > 1, then restored the order alone: no model, no claim about who shares a queue, and the reducer keeps a
+        # communication stream of its own.
+        from .functional import pretouch_streams
+        pretouch_streams(device, ['decode', 'aux', 'burn', 'burn', 'side'])
     if os.environ.get('S4F_EAGER_SGD', '1') != '0':
         # parameter ranges are updated as soon as their (all-reduced) gradient is final, behind the rest of backward
         optimizer.attach_eager(model.student_store, reducer if collectives_active() else None, reducer.grad_scale())

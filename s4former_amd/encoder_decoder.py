@@ -174,11 +174,13 @@ class BaseSegmentor(BaseModule):
 
 
 def _lockstep_on(var):
-    v = os.environ.get(var, 'auto')
-    if v == 'auto':
-        from .dist import collectives_active
-        return collectives_active()
-    return v == '1'
+    """S4F_AUX_LOCKSTEP / S4F_DECODE_LOCKSTEP = 1 | 0 (default; 'auto' is read as 0 since round 4).  Round 3 turned the lockstep
+    on whenever the step exchanges anything (fewer SyncBN exchanges: 32 -> 12 per step; -0.47 ms through a one-rank RCCL group
+    then).  Measured again on the round-4 tree with the same tool (tools/exp/rccl_ab3.sh, one box, 28.38 ms without a process
+    group): both off 28.72 ms, auxiliary heads in lockstep 29.59, decode head in lockstep 30.70, both 30.70 - the heads lose
+    more overlap with each other than the 20 saved exchanges cost at one rank.  What an exchange costs with peers is unmeasured
+    (DESIGN section 6): the switches stay, parity-tested at world 2 in both settings."""
+    return os.environ.get(var, '0') == '1'
 
 
 _UNSUP_STREAM = os.environ.get('S4F_UNSUP_STREAM', 'decode')    # experiment: 'decode2' = a third head stream
@@ -368,9 +370,8 @@ class EncoderDecoder(BaseSegmentor):
 
     def _aux_lockstep(self):
         """The structurally identical auxiliary heads advance layer by layer together, one SyncBN exchange per layer for all four
-        (16 -> 4 per step).  S4F_AUX_LOCKSTEP = 1 | 0 | auto (default): auto = on when the step exchanges anything (N > 1; round 3:
-        the world-2 parity tests and the one-rank RCCL run pass with it and it is the cheaper schedule there, 32.02 -> 31.57 ms with
-        the decode lockstep), off on one GPU - one head after the other, the path every single-GPU parity test runs."""
+        (16 -> 4 per step).  S4F_AUX_LOCKSTEP=1; off by default (see _lockstep_on): one head after the other, the path every
+        single-GPU parity test runs."""
         if not _lockstep_on('S4F_AUX_LOCKSTEP'):
             return False
         heads = list(self.auxiliary_head)
@@ -378,8 +379,8 @@ class EncoderDecoder(BaseSegmentor):
             len({(h.num_convs, h.channels, h.up_scale) for h in heads}) == 1
 
     def _decode_lockstep(self):
-        """S4F_DECODE_LOCKSTEP = 1 | 0 | auto (default): the decode head's calls of a step advance in lockstep too (8 fewer SyncBN
-        exchanges); auto = on at N > 1 like the auxiliary heads (unmeasured with peers: DESIGN section 6)."""
+        """S4F_DECODE_LOCKSTEP=1: the decode head's calls of a step advance in lockstep too (8 fewer SyncBN exchanges); off by
+        default (see _lockstep_on)."""
         return _lockstep_on('S4F_DECODE_LOCKSTEP') and hasattr(type(self.decode_head), 'fused_losses_lockstep')
 
     # ------------------------------------------------------------------ evaluation (SURVEY §8f-2)

@@ -95,10 +95,17 @@ class S4FSGD(torch.optim.Optimizer):
             if len(reducer._handles) > n0:
                 handle = reducer._handles[-1]
         _, plan = self._plan()
-        hit = [(ga, gb, idx) for _, ga, gb, idx in plan if ga <= a and b <= gb]
-        lm = self._uniform(hit[0][2]) if hit else None
-        if lm is None or store.grad is None:
-            return                                   # mixed learning rates inside the group: left to step()
+        # the parts of [a, b) that are parameters of ONE learning-rate setting each (a span may cover several adjacent head groups
+        # and the running statistics between them: those have no gradient and are not stepped)
+        pieces = []
+        for _, ga, gb, idx in plan:
+            lo, hi = max(a, ga), min(b, gb)
+            if lo < hi:
+                lm = self._uniform(idx)
+                if lm is not None:                   # (mixed learning rates inside a group: left to step())
+                    pieces.append((lo, hi, lm))
+        if not pieces or store.grad is None:
+            return
         from .functional import extra_streams, side_stream
         if handle is not None and reducer._stream is not None:
             stream = reducer._stream                 # behind the all-reduce of this very range
@@ -122,11 +129,13 @@ class S4FSGD(torch.optim.Optimizer):
         with torch.cuda.stream(stream):
             if handle is not None:
                 handle.wait()
-            pt = store.flat_t[a:b] if store.flat_t is not None else None
-            K.sgd_momentum(store.flat[a:b], store.grad[a:b], store.mom[a:b], pt, b - a, lm[0], lm[1], scale,
-                           store.first_sgd_step, store.dtype, zero_grad=self.fused_zero_grad)
+            for lo, hi, lm in pieces:
+                pt = store.flat_t[lo:hi] if store.flat_t is not None else None
+                K.sgd_momentum(store.flat[lo:hi], store.grad[lo:hi], store.mom[lo:hi], pt, hi - lo, lm[0], lm[1], scale,
+                               store.first_sgd_step, store.dtype, zero_grad=self.fused_zero_grad)
             store.sync_T_range(a, b)                 # the transposed operand shadows of this range, behind its update
-        self._eager_done.append((a, b, stream))
+        for lo, hi, _ in pieces:
+            self._eager_done.append((lo, hi, stream))
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):

@@ -9,6 +9,8 @@ each become one launch over a contiguous range instead of a Python loop over ~20
 3x3 conv weights are stored physically as [co][ky][kx][ci] (torch channels_last strides on the logical
 [co,ci,ky,kx] parameter): that is the B-operand layout of the implicit-GEMM kernels.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -25,6 +27,10 @@ def _is_conv3x3(t):
 class _Entry:
     __slots__ = ('module', 'attr', 'is_param', 'name', 'group', 'shape', 'numel', 'off', 'cl', 'v_phys', 'v_grad', 'v_shadow',
                  'v_T')
+
+
+# A/B switch (round 4): hand a parameter group's pending spans to the reducer as soon as its last range is final
+GROUP_FLUSH = os.environ.get('S4F_GROUP_FLUSH', '1') != '0'
 
 
 class ParamStore:
@@ -329,10 +335,13 @@ class ParamStore:
         ep = getattr(self, 'step_epoch', 0)
         if getattr(self, '_co_epoch', None) != ep:
             self._co, self._co_epoch = [], ep           # spans left pending by the previous step were covered by reduce_() / step()
-        ga, gb = a, b
+        ga, gb = self._flush_unit(a, b, cmin)
+        # a span that ends where a group's parameters end also takes the group's tail (BatchNorm running statistics: no
+        # gradients, zeros in the gradient arena) - so that the spans of adjacent head groups touch and merge instead of
+        # leaving ten collectives (five heads + five 1,024-element tails at the end of the step) where one will do
         for rng in self.group_ranges.values():
-            if rng['all'][0] <= a and b <= rng['all'][1]:
-                ga, gb = rng['all']
+            if b == rng['params'][1] and a >= rng['all'][0]:
+                b = rng['all'][1]
                 break
         # merge with pending neighbours inside the group
         merged = True
@@ -348,18 +357,41 @@ class ParamStore:
             cb(a, b)
         else:
             self._co.append((a, b))
-        # round 4: a parameter group none of whose ranges is still pending (no node of this step will write into it any more) is
-        # handed on AT ONCE, whatever its size - the reference's DDP reducer fires a bucket as soon as it is ready
+        # round 4: a flush unit (_flush_unit: a parameter group, or the run of small adjacent head groups) none of whose ranges is
+        # still pending (no node of this step will write into it any more) is handed on AT ONCE, whatever its size - the reference's DDP reducer fires a bucket as soon as it is ready
         # (mmseg/apis/train.py:129-138).  The decode head (3.5 M) and the auxiliary heads (9.5 M) never reach coalesce_min; parked
         # until reduce_() their all-reduce + SGD sat on the critical path behind the whole backward although their gradients are
         # final before the backbone's backward starts.
         pend = getattr(self, '_pend', None) or {}
-        if not any(ga <= pa and pb <= gb for (pa, pb) in pend):
+        if GROUP_FLUSH and not any(ga <= pa and pb <= gb for (pa, pb) in pend):
             mine = sorted(sp for sp in self._co if ga <= sp[0] and sp[1] <= gb)
             if mine:
                 self._co = [sp for sp in self._co if not (ga <= sp[0] and sp[1] <= gb)]
                 for sa, sb in mine:
                     cb(sa, sb)
+
+    def _flush_unit(self, a, b, cmin):
+        """[ua, ub): the stretch of the arena inside which spans are merged and which is handed on as soon as none of its ranges
+        is pending: a parameter group, or a run of ADJACENT groups that are each smaller than coalesce_min (the decode head and the
+        four auxiliary heads, 13 M elements together: one all-reduce + one SGD for all of them instead of five)."""
+        key = (cmin, len(self.group_ranges))
+        if getattr(self, '_units_key', None) != key:
+            units, run = [], None
+            for rng in sorted(r['all'] for r in self.group_ranges.values()):
+                small = rng[1] - rng[0] < cmin
+                if small and run is not None and run[1] == rng[0]:
+                    run[1] = rng[1]
+                elif small:
+                    run = [rng[0], rng[1]]
+                    units.append(run)
+                else:
+                    run = None
+                    units.append([rng[0], rng[1]])
+            self._units, self._units_key = [tuple(u) for u in units], key
+        for ua, ub in self._units:
+            if ua <= a and b <= ub:
+                return ua, ub
+        return a, b
 
     # A range is FINAL when the last node that accumulates into it has run its backward.  A node announces itself in its
     # forward (range_acquire) and signs off at the end of its backward (range_release); the counts restart with every step

@@ -111,15 +111,17 @@ VARIANTS = {
     'no_eager_sgd': dict(S4F_EAGER_SGD='0'),
     'lockstep_heads': dict(S4F_AUX_LOCKSTEP='1', S4F_DECODE_LOCKSTEP='1'),
     # round 3: final ranges merged two tiny layers at a time (the production size merges three DeiT-B layers), and the round-2
-    # schedule (one head after the other, one collective per range) now that lockstep + coalescing are the N > 1 defaults
+    # schedule (one collective per range).  Round 4: the head lockstep is opt-in again (the default runs one head after the other);
+    # the empirical first-use order of the streams has its own switch
     'coalesced_buckets': dict(S4F_BUCKET_MIN_ELEMS='1500000'),
     'round2_schedule': dict(S4F_AUX_LOCKSTEP='0', S4F_DECODE_LOCKSTEP='0', S4F_BUCKET_MIN_ELEMS='1'),
+    'natural_stream_order': dict(S4F_STREAM_ORDER='0'),
 }
 
 
 @pytest.mark.parametrize('variant,flags', [('default', 'pasa'), ('default', 'plain'), ('no_eager_sgd', 'pasa'),
                                            ('lockstep_heads', 'pasa'), ('coalesced_buckets', 'pasa'),
-                                           ('round2_schedule', 'plain')])
+                                           ('round2_schedule', 'plain'), ('natural_stream_order', 'plain')])
 def test_two_ranks_equal_one_rank_on_the_concatenated_batch(variant, flags, single, tmp_path):
     d = str(tmp_path)
     port = 29600 + sorted(VARIANTS).index(variant) * 2 + (flags == 'plain')

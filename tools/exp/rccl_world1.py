@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 import s4former_amd.dist as D          # noqa: E402
 import s4former_amd.functional as F_   # noqa: E402
 
-CALLS = dict(grad=0, bn=0)
+CALLS = dict(grad=0, bn=0, sizes=[])
 
 
 def _reduce(self):
@@ -44,6 +44,7 @@ if __name__ == '__main__':
 
     def _issue(t):
         CALLS['grad'] += 1
+        CALLS['sizes'].append(int(t.numel()))
         return issue0(t)
     if only != 'bn':
         D.GradReducer.issue = staticmethod(_issue)
@@ -60,4 +61,5 @@ if __name__ == '__main__':
     finally:
         print(f'[rccl_world1] backend {dist.get_backend()}, collectives issued: gradient ranges {CALLS["grad"]}, '
               f'SyncBN exchanges {CALLS["bn"]}', flush=True)
+        print('[rccl_world1] elements of the last 32 gradient collectives:', CALLS['sizes'][-32:], flush=True)
         dist.destroy_process_group()
