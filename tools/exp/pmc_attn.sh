@@ -12,7 +12,7 @@ for p in ('p1', 'p2'):
     for f in glob.glob(f'{out}/{p}/**/*counter_collection.csv', recursive=True):
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f)):
-            if 'attn' in r['Kernel_Name'] or 'fb::' in r['Kernel_Name'] or '2fb' in r['Kernel_Name'] or '2ff' in r['Kernel_Name']:
+            if 'attn' in r['Kernel_Name'] or 'fb::' in r['Kernel_Name'] or 'ff::' in r['Kernel_Name'] or '2fb' in r['Kernel_Name'] or '2ff' in r['Kernel_Name']:
                 agg[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k, d in agg.items():
             print(p, k)
