@@ -97,7 +97,11 @@ typedef struct s4f_gemm_desc {
   /* round 3: resid_t != 0 (bf16 mode only): `resid` points at T (bf16) values - the residual stream kept in the operand
    * type; the sum leaves through out_t (out_f32 may be NULL).  Implemented by the coalesced epilogues (N % 8 == 0). */
   int32_t resid_t;
-  int32_t reserved0;
+  /* round 5: gelu_q8 != 0 (bf16 mode only): the gelu' tensor (out_pre of S4F_ACT_GELU, aux of S4F_ACT_GELU_BWD) is 8-bit
+   * fixed point, one byte per element: code = rint(192 gelu') + 25 (gelu' in [-0.129, 1.129]; step 1/192; 0, 0.5, 1 exact);
+   * ldo_pre / ld_aux count bytes = elements.  Halves what the fc1 epilogue writes beside its output and what the fc2
+   * input-gradient epilogue reads (50 MB each way per layer at 16 x 1025 tokens). */
+  int32_t gelu_q8;
 } s4f_gemm_desc;            /* 216 bytes (the kernels take the descriptor by value inside their argument struct) */
 
 int s4f_gemm(const s4f_gemm_desc* d, s4f_stream stream);
@@ -200,7 +204,8 @@ typedef struct s4f_layer_desc {
   int32_t dtype, xdtype;
   float eps, bias_w;
   int32_t hint[8];
-  int32_t wg_hint, wg_splitk, fold_colsum, reserved0;
+  int32_t wg_hint, wg_splitk, fold_colsum;
+  int32_t gelu_q8;                       /* round 5: gelu_d is uint8 [B N, F] (s4f_gemm_desc.gelu_q8); bf16 mode only */
   /* parameters: fp32 masters, operand-typed shadows [out][in], transposed shadows [in][out] (bf16 backward; NULL in fp32) */
   const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *bqkv, *bo, *b1, *b2;
   const void *wqkv, *wo, *w1, *w2;
@@ -208,7 +213,7 @@ typedef struct s4f_layer_desc {
   /* PASA rank-1 attention bias (vit.py:519-535) or NULL */
   const float *bias_u, *row_flag;
   /* forward: x X [B,N,E] in; saved for the backward: xn T, mean1 / rstd1 fp32 [B N], qkv T [B,N,3E], ctx T, lse fp32 [B,H,N],
-   * x1 X, xn2 T, mean2 / rstd2, gelu_d T [B N, F] (gelu'; NULL = not written: no backward will follow), a T [B N, F]; x2 X out */
+   * x1 X, xn2 T, mean2 / rstd2, gelu_d T (uint8 with gelu_q8) [B N, F] (gelu'; NULL = not written: no backward will follow), a T [B N, F]; x2 X out */
   const void* x; void* xn; float* mean1; float* rstd1; void* qkv; void* ctx; float* lse; void* x1; void* xn2; float* mean2; float* rstd2;
   void* gelu_d; void* a; void* x2;
   /* backward: g2 X (gradient of x2), g2t its T copy (== g2 when X is T), g2cs fp32 [E] column sums of g2 or NULL (computed here);

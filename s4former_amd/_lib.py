@@ -39,7 +39,7 @@ class GemmDesc(Structure):
         ('act', c_int32), ('atomic', c_int32),
         ('pos_period', c_int32), ('tile_hint', c_int32), ('pos', c_void_p),
         ('colsum', c_void_p),
-        ('resid_t', c_int32), ('reserved0', c_int32),
+        ('resid_t', c_int32), ('gelu_q8', c_int32),
     ]
 assert ctypes.sizeof(GemmDesc) == 216, 'GemmDesc must mirror s4f_gemm_desc (include/s4f.h, static_assert in gemm.hip)'
 
@@ -47,7 +47,7 @@ assert ctypes.sizeof(GemmDesc) == 216, 'GemmDesc must mirror s4f_gemm_desc (incl
 class LayerDesc(Structure):
     """mirror of s4f_layer_desc (include/s4f.h)"""
     _fields_ = ([(n, c_int32) for n in ('B', 'N', 'E', 'F', 'H', 'dtype', 'xdtype')] + [('eps', c_float), ('bias_w', c_float)] +
-                [('hint', c_int32 * 8), ('wg_hint', c_int32), ('wg_splitk', c_int32), ('fold_colsum', c_int32), ('reserved0', c_int32)] +
+                [('hint', c_int32 * 8), ('wg_hint', c_int32), ('wg_splitk', c_int32), ('fold_colsum', c_int32), ('gelu_q8', c_int32)] +
                 [(n, c_void_p) for n in (
                     'ln1_g', 'ln1_b', 'ln2_g', 'ln2_b', 'bqkv', 'bo', 'b1', 'b2', 'wqkv', 'wo', 'w1', 'w2', 'wqkv_T', 'wo_T', 'w1_T', 'w2_T',
                     'bias_u', 'row_flag',

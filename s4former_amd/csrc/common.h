@@ -182,6 +182,24 @@ __device__ __forceinline__ void gelu_pair(float z, float& y, float& dy) {
   }
 }
 
+// gelu'(z) as 8-bit fixed point (round 5, s4f_gemm_desc.gelu_q8): gelu' lies in [-0.1290, 1.1290]; code = rint(192 gelu') + 25
+// covers [-25/192, 230/192] with step 1/192 (absolute error <= 1/384 = 0.0026, what bf16 resolves in [0.5, 1]); 0, 0.5 and 1
+// are exact.  Halves the bytes of the tensor the fc1 epilogue writes and the fc2 input-gradient epilogue reads (vit.py:86-103).
+__device__ __forceinline__ uint32_t gelu_d_q8(float gd) {
+  return (uint32_t)(int)fminf(fmaxf(rintf(fmaf(gd, 192.f, 25.f)), 0.f), 255.f);
+}
+__device__ __forceinline__ float gelu_d_dq8(uint32_t code) { return ((float)code - 25.f) * (1.f / 192.f); }
+// 8 codes <-> two 32-bit words (element e in byte e)
+__device__ __forceinline__ uint2 gelu_d_q8x8(const float (&gd)[8]) {
+  uint2 w;
+  w.x = gelu_d_q8(gd[0]) | (gelu_d_q8(gd[1]) << 8) | (gelu_d_q8(gd[2]) << 16) | (gelu_d_q8(gd[3]) << 24);
+  w.y = gelu_d_q8(gd[4]) | (gelu_d_q8(gd[5]) << 8) | (gelu_d_q8(gd[6]) << 16) | (gelu_d_q8(gd[7]) << 24);
+  return w;
+}
+__device__ __forceinline__ float gelu_d_dq8_at(const uint2 w, int e) {
+  return gelu_d_dq8(((e < 4 ? w.x : w.y) >> (8 * (e & 3))) & 0xffu);
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: set it once per (kernel, device), not

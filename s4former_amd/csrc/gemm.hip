@@ -277,10 +277,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs args) {
         if (d.act == S4F_ACT_GELU) {
           float gy, gd;
           gelu_pair<sizeof(T) == 4>(v, gy, gd);
-          if (out_pre) out_pre[orow * d.ldo_pre + n] = from_f32<T>(gd);
+          if (out_pre) {
+            if (d.gelu_q8) reinterpret_cast<uint8_t*>(d.out_pre)[orow * d.ldo_pre + n] = (uint8_t)gelu_d_q8(gd);
+            else out_pre[orow * d.ldo_pre + n] = from_f32<T>(gd);
+          }
           v = gy;
         } else if (d.act == S4F_ACT_GELU_BWD) {
-          v *= to_f32<T>(aux[(long)m * d.ld_aux + n]);
+          v *= d.gelu_q8 ? gelu_d_dq8(reinterpret_cast<const uint8_t*>(d.aux)[(long)m * d.ld_aux + n]) : to_f32<T>(aux[(long)m * d.ld_aux + n]);
         }
         if (d.resid && first_split) v += d.resid_t ? (float)reinterpret_cast<const bf16_t*>(d.resid)[orow * d.ldr + n] : reinterpret_cast<const float*>(d.resid)[orow * d.ldr + n];
         if (d.out_f32) {
@@ -335,7 +338,7 @@ static int pick_tile(const s4f_gemm_desc& d) {
   if (d.tile_hint == 1) return 0;
   if (d.tile_hint == 2) return 128;
   if (d.tile_hint == 3 || d.tile_hint == 4) return 256;
-  if (d.tile_hint >= 10 && d.tile_hint <= 12) return 2048;                       // 8-wave ping-pong kernel (gemm5.hip)
+  if (d.tile_hint >= 10 && d.tile_hint <= 14) return 2048;                       // 8-wave ping-pong kernel (gemm5.hip)
   if (d.tile_hint == 8 || d.tile_hint == 9) return 192;     // 256 x 192 tile, 16 / 8 waves (token GEMMs with N = 768, 2304)
   const long sk = d.splitk < 1 ? 1 : d.splitk;
   const long t256 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 256) * sk;
@@ -360,6 +363,8 @@ S4F_API int s4f_gemm(const s4f_gemm_desc* dp, s4f_stream stream) {
   S4F_CHECK(d.splitk <= 1 || (d.atomic && d.out_f32 && !d.out_t && d.act == S4F_ACT_NONE),
             "s4f_gemm: splitk > 1 needs atomic fp32 output and no activation");
   S4F_CHECK(d.act != S4F_ACT_GELU_BWD || d.aux, "s4f_gemm: GELU_BWD needs aux");
+  S4F_CHECK(!d.gelu_q8 || (d.dtype == S4F_BF16 && (d.act == S4F_ACT_GELU || d.act == S4F_ACT_GELU_BWD)),
+            "s4f_gemm: gelu_q8 is the bf16 mode's 8-bit gelu' (S4F_ACT_GELU / S4F_ACT_GELU_BWD only)");
   // contraction chunks must not straddle K (row modes: K % epc; k modes: any K)
   // both operands contraction-contiguous: chunks must not straddle K.  With a k-major operand the rows >= K of
   // that operand are zero-filled, so the other operand may carry (finite) padding up to its 16-B chunk.

@@ -246,10 +246,13 @@ __device__ __forceinline__ void epilogue_quad(const s4f_gemm_desc& d, f32x4 a, i
     if (d.act == S4F_ACT_GELU) {
       float gy, gd;
       gelu_pair<false>(v, gy, gd);
-      if (out_pre) out_pre[(long)m * d.ldo_pre + n] = (bf16_t)gd;
+      if (out_pre) {
+        if (d.gelu_q8) reinterpret_cast<uint8_t*>(d.out_pre)[(long)m * d.ldo_pre + n] = (uint8_t)gelu_d_q8(gd);
+        else out_pre[(long)m * d.ldo_pre + n] = (bf16_t)gd;
+      }
       v = gy;
     } else if (d.act == S4F_ACT_GELU_BWD) {
-      v *= (float)aux[(long)m * d.ld_aux + n];
+      v *= d.gelu_q8 ? gelu_d_dq8(reinterpret_cast<const uint8_t*>(d.aux)[(long)m * d.ld_aux + n]) : (float)aux[(long)m * d.ld_aux + n];
     }
     if (d.resid && first_split) v += resid_at(d, (long)m * d.ldr + n);
     if (d.out_f32) {
@@ -318,19 +321,33 @@ __device__ __forceinline__ void epilogue_rows(const s4f_gemm_desc& d, const floa
           for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
         }
         if (d.act == S4F_ACT_GELU) {
-          bf16x8 pv;
+          float gdv[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            float gy, gd;
-            gelu_pair<false>(v[e], gy, gd);
+            float gy;
+            gelu_pair<false>(v[e], gy, gdv[e]);
             v[e] = gy;
-            pv[e] = (bf16_t)gd;
           }
-          if (out_pre) EPI_STORE(reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n), pv);
-        } else if (d.act == S4F_ACT_GELU_BWD) {
-          const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
+          if (out_pre) {
+            if (d.gelu_q8) {
+              EPI_STORE(reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(d.out_pre) + (long)m * d.ldo_pre + n), gelu_d_q8x8(gdv));
+            } else {
+              bf16x8 pv;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] *= (float)z[e];
+              for (int e = 0; e < 8; ++e) pv[e] = (bf16_t)gdv[e];
+              EPI_STORE(reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n), pv);
+            }
+          }
+        } else if (d.act == S4F_ACT_GELU_BWD) {
+          if (d.gelu_q8) {
+            const uint2 z = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(d.aux) + (long)m * d.ld_aux + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= gelu_d_dq8_at(z, e);
+          } else {
+            const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= (float)z[e];
+          }
         }
         if (d.resid && first_split) {
           if (d.resid_t) {

@@ -383,6 +383,7 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
     __syncthreads();
     constexpr int NROWS = TAIL ? 256 + TAIL_MAX : 256;
     const int act = d.act;
+    const bool q8 = d.gelu_q8 != 0;                  // gelu' as 8-bit fixed point (common.h)
     float cs[8], cq[8];                              // column sums (and sums of squares) of what this thread stores (its 8 columns never change)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
@@ -394,19 +395,33 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
       bf16x8 v = *reinterpret_cast<const bf16x8*>(tb + row * LDB + cc * 8);
       const int n = n0 + cc * 8;
       if (act == S4F_ACT_GELU) {
-        bf16x8 pv;
+        float gdv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float gy, gd;
-          gelu_pair<false>((float)v[e], gy, gd);
+          float gy;
+          gelu_pair<false>((float)v[e], gy, gdv[e]);
           v[e] = (bf16_t)gy;
-          pv[e] = (bf16_t)gd;
         }
-        if (out_pre) *reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n) = pv;
-      } else if (act == S4F_ACT_GELU_BWD) {
-        const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
+        if (out_pre) {
+          if (q8) {
+            *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(d.out_pre) + (long)m * d.ldo_pre + n) = gelu_d_q8x8(gdv);
+          } else {
+            bf16x8 pv;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * (float)z[e]);
+            for (int e = 0; e < 8; ++e) pv[e] = (bf16_t)gdv[e];
+            *reinterpret_cast<bf16x8*>(out_pre + (long)m * d.ldo_pre + n) = pv;
+          }
+        }
+      } else if (act == S4F_ACT_GELU_BWD) {
+        if (q8) {
+          const uint2 z = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(d.aux) + (long)m * d.ld_aux + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * gelu_d_dq8_at(z, e));
+        } else {
+          const bf16x8 z = *reinterpret_cast<const bf16x8*>(aux + (long)m * d.ld_aux + n);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] * (float)z[e]);
+        }
       } else if (res_t) {
         const bf16x8 rr = *reinterpret_cast<const bf16x8*>(res_t + (long)m * d.ldr + n);
 #pragma unroll
@@ -498,6 +513,522 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
   });
 }
 
+// =============================================================================================== persistent form (round 5)
+// The same ping-pong K loop, but ONE workgroup per CU walks its tiles and the stream of LDS-DMA never stops at a tile
+// boundary: the parts of the next tile's first two K-tiles are issued in the slots where the one-tile kernel issues
+// out-of-range dummies, so a tile's first-DMA latency (3.3 us per round of tiles) is paid once per launch.  What makes that
+// possible is an epilogue that needs NO LDS (the 128 KiB ring cannot hold a staged output tile and the next tile's operands):
+// the MFMA operands are swapped (D = B A^T: a lane then holds four consecutive COLUMNS of one row) and a lane's B fragment of
+// sub-tile j is read from row c0 + 8 (li >> 2) + 4 j + (li & 3) of the B image, so that after the two sub-tiles of a 32-column
+// half lane (li, g) owns the eight consecutive columns c0 + 8 g .. + 7 of row li: one 16-byte store per (row tile, half)
+// straight from the accumulators, activation applied in registers, no barrier, each wave on its own.  (B image swizzle:
+// chunk ^ (row & 7) ^ 4 (row >> 3 & 1), so that the eight rows {0..3, 8..11} + 4 j a quarter-wave reads stay conflict-free.)
+// The bias enters as the START VALUE of the accumulators (loaded for the next tile while the current one is written out).
+// The stores of tile i are still in flight when the K loop of tile i + 1 starts: gfx950 counts loads, stores and LDS-DMA on one
+// in-order counter, so the counted waits of the first K-tile behind an epilogue allow for the NST stores that sit between the
+// prefetched parts and the parts issued after them (vmcnt(8 + NST)); from the second K-tile on the plain count applies.
+// Only the T-output epilogues of the dense token GEMMs (bias; GELU + gelu'; x gelu' with folded column sums) take this path.
+#ifndef G5P_AUTO
+#define G5P_AUTO 1        // 0: tile_hint 10 never takes the persistent form (same-box A/B builds)
+#endif
+constexpr int G5P_TAB = 2 * G5_BUF + 2 * G5_TAILB;   // LDS offset of the workgroup's tile table: int2 (tm, tn) per tile, (-1, -1) behind the last
+constexpr int G5P_MAXT = 126;                        // tiles per workgroup the table holds (1 KiB)
+constexpr int G5P_BIAS = G5P_TAB + (G5P_MAXT + 2) * 8;   // bias slots: [tile parity][wave][64 floats] = 4 KiB
+constexpr int G5P_LDS = G5P_BIAS + 2 * 8 * 256;
+struct TileSeq {                                    // tiles of this workgroup: XCD-contiguous ranges, grouped order (gemm2.hip)
+  unsigned tab_addr;                                 // LDS byte address of the table
+  int n, tiles_m;
+  // called by all threads at kernel entry (ends with a barrier): thread j < n computes tile j once (the integer divisions of
+  // the grouped order), every later lookup is one wave-uniform LDS read
+  __device__ __forceinline__ void init(const GemmArgs& a, int nwg, char* smem) {
+    tiles_m = a.tiles_m;
+    const int tiles_n = a.tiles_n;
+    const int nt = tiles_m * tiles_n;
+    const int w = blockIdx.x, xcd = w & 7, q8 = nt >> 3, r8 = nt & 7;
+    const int slot = w >> 3, nper = nwg >> 3;
+    const int base = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0);
+    n = slot < cnt ? (cnt - slot + nper - 1) / nper : 0;
+    int2* t = reinterpret_cast<int2*>(smem + G5P_TAB);
+    tab_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(smem + G5P_TAB);
+    const int j = threadIdx.x;
+    if (j <= G5P_MAXT + 1) {
+      int2 v = make_int2(-1, -1);
+      if (j < n) {
+        const int L = base + j * nper + slot;
+        constexpr int GM = 8;
+        const int per_group = GM * tiles_n;
+        const int grp = L / per_group, r = L - grp * per_group;
+        const int rows_here = min(GM, tiles_m - grp * GM);
+        v.x = grp * GM + r % rows_here;
+        v.y = r / rows_here;
+      }
+      t[j] = v;
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ int count() const { return n; }
+  // (inline asm: behind a compiler-visible read of this table hipcc drains vmcnt(0) - the LDS-DMA of the K loop in flight -
+  //  at every tile switch of every part)
+  __device__ __forceinline__ bool tile(int j, int& tm, int& tn) const {     // j <= n (n = the sentinel)
+    typedef __attribute__((ext_vector_type(2))) int i32x2;
+    i32x2 v;
+    const unsigned addr = tab_addr + 8u * (unsigned)j;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    tm = __builtin_amdgcn_readfirstlane(v[0]);
+    tn = __builtin_amdgcn_readfirstlane(v[1]);
+    return tm >= 0;
+  }
+};
+
+// dense row-major feeder whose parts walk the workgroup's tile sequence on their own (each part crosses a tile boundary in
+// its own phase)
+template <bool IS_A>
+struct DFeeder {
+  __amdgpu_buffer_rsrc_t rsrc;
+  long ld;
+  int lim, nk, wave, lane8, chunk;
+  int voff[4];
+  int kp[2], jp[2];
+  int tvoff, tail_rows, M;
+
+  __device__ __forceinline__ int block_of(int u) const {
+    const int part = u >> 1, i = u & 1;
+    if constexpr (IS_A) return wave + 16 * i + 8 * part;
+    const int e = wave + 8 * i;
+    return 8 * (e >> 2) + (e & 3) + 4 * part;
+  }
+  template <int PART>
+  __device__ __forceinline__ void set_tile(const TileSeq& ts, int j) {
+    int tm, tn;
+    const bool ok = ts.tile(j, tm, tn);
+    const int blk0 = (IS_A ? tm : tn) * 256;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = 2 * PART + i;
+      const int gi = blk0 + 8 * block_of(u) + lane8;
+      voff[u] = (ok && gi < lim) ? (int)(((long)gi * ld + chunk * 8) * 2) : G5_OOB;
+    }
+    if constexpr (IS_A && PART == P_AL) {
+      tvoff = G5_OOB;
+      if (ok && tail_rows > 0 && tm == ts.tiles_m - 1 && wave < 2) {
+        const int gi = blk0 + BM + 8 * wave + lane8;
+        if (gi < M) tvoff = (int)(((long)gi * ld + chunk * 8) * 2);
+      }
+    }
+  }
+  __device__ __forceinline__ void init(const s4f_gemm_desc& d, const TileSeq& ts, int nk_, int tail_rows_) {
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    lane8 = lane >> 3;
+    ld = IS_A ? d.lda : d.ldb;
+    lim = IS_A ? d.M : d.N;
+    M = d.M; nk = nk_; tail_rows = tail_rows_;
+    const long bytes = ((long)(lim - 1) * ld + d.K) * 2;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(IS_A ? d.A : d.B), 0, (int)bytes, 0x00020000);
+    // A: chunk ^ (row & 7); B: chunk ^ (row & 7) ^ 4 (bit 3 of the row) - bit 3 of a B row is bit 0 of its 8-row block = wave & 1
+    chunk = (lane & 7) ^ lane8 ^ (IS_A ? 0 : ((wave & 1) << 2));
+    kp[0] = kp[1] = 0; jp[0] = jp[1] = 0;
+    tvoff = G5_OOB;
+    set_tile<0>(ts, 0);
+    set_tile<1>(ts, 0);
+  }
+  // part PART of the part's next K-tile into the image at img (A / AL: + the folded tail rows into timg)
+  template <int PART>
+  __device__ __forceinline__ void issue(const TileSeq& ts, char* img, char* timg = nullptr) {
+    if (kp[PART] == nk) {                            // wave-uniform: the part moves on to the workgroup's next tile
+      kp[PART] = 0;
+      ++jp[PART];
+      set_tile<PART>(ts, jp[PART]);
+    }
+    const int so = kp[PART] * (BK * 2);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int u = 2 * PART + i;
+      bufl16(rsrc, voff[u], so, img + block_of(u) * 1024);
+    }
+    if constexpr (IS_A && PART == P_AL) bufl16(rsrc, tvoff, so, timg + wave * 1024);
+    ++kp[PART];
+  }
+};
+
+// B fragment of sub-tile j (0 / 1) of a 32-column half, permuted rows + the B swizzle of the persistent form.  The half starts at
+// a multiple of 32 rows, so with b = (li >> 2) & 1:  row & 7 = 4 j + (li & 3),  row bit 3 = b,  and the 16-byte chunk of
+// k-step s is ((g ^ (li & 3)) | ((s ^ j ^ b) << 2)): TWO lane-dependent byte offsets (s ^ j = 0 / 1, 64 bytes apart) serve every
+// read; everything else is the wave's base address and an immediate.
+struct BPerm {
+  int off0;                                          // (8 (li >> 2) + (li & 3)) * 128 + 16 ((g ^ (li & 3)) | (b << 2))
+  __device__ __forceinline__ void init() {
+    const int l = threadIdx.x & 63, g = l >> 4, li = l & 15, b = (li >> 2) & 1;
+    off0 = (8 * (li >> 2) + (li & 3)) * 128 + 16 * ((g ^ (li & 3)) | (b << 2));
+  }
+  // half_base = image + 128 * (first row of the half)
+  template <int J, int S>
+  __device__ __forceinline__ void read(Frag<bf16_t>& f, const char* half_base) const {
+    lds_read_lin(f, half_base + (off0 ^ ((S ^ J) << 6)) + J * 512);
+  }
+};
+
+template <int ACT, int DBG = 0>
+__global__ __launch_bounds__(512) void gemm5p_kernel(const GemmArgs args, const int nwg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const s4f_gemm_desc& d = args.d;
+  TileSeq ts;
+  ts.init(args, nwg, smem);
+  const int nmine = ts.count();
+  if (nmine == 0) return;
+  const int nk = args.nk;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l = threadIdx.x & 63, g = l >> 4, li = l & 15;
+  const bool q8 = d.gelu_q8 != 0;
+
+  DFeeder<true> fa;
+  DFeeder<false> fb;
+  fa.init(d, ts, nk, args.tail_rows);
+  fb.init(d, ts, nk, 0);
+
+  f32x4 acc[8][4];
+  f32x4 tacc[2];
+  // start values of the accumulators of tile j: the bias of the lane's columns (n0 + 64 wc + 32 BH + 8 g + 4 jj + r)
+  auto opaque = [](int v) __attribute__((always_inline)) { asm volatile("" : "+v"(v)); return v; };
+  // The bias of tile j's 64 columns of this wave travels by ONE 256-byte LDS-DMA into the wave's own slot (tile parity), issued
+  // at the head of the epilogue of tile j - 1 (kernel entry for j = 0) and read back - inline asm again - when the accumulators
+  // are started: no load whose result the compiler would wait for with vmcnt(0) behind the epilogue's stores.
+  __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias ? d.bias : reinterpret_cast<const float*>(d.B)), 0,
+                                                                    d.bias ? d.N * 4 : 0, 0x00020000);
+  auto bias_fetch = [&](int j) __attribute__((always_inline)) {
+    if (!d.bias) return;
+    int tm, tn;
+    if (!ts.tile(j, tm, tn)) return;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(brsrc, (__attribute__((address_space(3))) void*)(smem + G5P_BIAS + (j & 1) * 2048 + wave * 256), 4,
+                                             (threadIdx.x & 63) * 4, (tn * 256 + wc * 64) * 4, 0, 0);
+  };
+  // start values of the accumulators of tile j: the bias of the lane's columns (64 wc + 32 BH + 8 g + 4 jj + r)
+  auto acc_init = [&](int j) __attribute__((always_inline)) {
+    f32x4 bv[4];
+    if (d.bias) {
+      const int g = opaque(l) >> 4;                   // (recomputed here: nothing of this may be hoisted into the K loop's registers)
+      const unsigned a0 = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)(smem + G5P_BIAS) + (j & 1) * 2048 + wave * 256 + 32 * g;
+      asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %4 offset:128\n\tds_read_b128 %3, %4 offset:144\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&v"(bv[0]), "=&v"(bv[1]), "=&v"(bv[2]), "=&v"(bv[3]) : "v"(a0) : "memory");
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bv[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[i][c] = bv[c];
+    tacc[0] = wr ? bv[2] : bv[0]; tacc[1] = wr ? bv[3] : bv[1];
+  };
+  bias_fetch(0);
+
+  // ---- prologue: K-tile 0 complete, AL / BL of K-tile 1
+  {
+    char* b0 = smem;
+    char* b1 = smem + G5_BUF;
+    fa.template issue<P_AL>(ts, b0, smem + G5_TAIL0);
+    fb.template issue<P_BL>(ts, b0 + G5_A);
+    fb.template issue<P_BH>(ts, b0 + G5_A);
+    fa.template issue<P_AH>(ts, b0);
+    fa.template issue<P_AL>(ts, b1, smem + G5_TAIL0 + G5_TAILB);
+    fb.template issue<P_BL>(ts, b1 + G5_A);
+  }
+  asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  acc_init(0);                                       // (the bias DMA is older than the nine parts left in flight)
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();         // stagger: the lower half runs one barrier behind
+
+  Frag<bf16_t> a[4][2], bl[2][2], bh[2][2], ta[2];
+  auto read_a = [&](const char* As, int half) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) frag_row<false>(a[i][s], As, wr * 128 + half * 64 + i * 16, s);
+  };
+  BPerm bp;
+  bp.init();
+  auto read_b = [&](Frag<bf16_t> (&b)[2][2], const char* Bs, int half) __attribute__((always_inline)) {
+    const char* hb = Bs + (wc * 64 + half * 32) * 128;
+    bp.read<0, 0>(b[0][0], hb); bp.read<1, 0>(b[1][0], hb);
+    bp.read<0, 1>(b[0][1], hb); bp.read<1, 1>(b[1][1], hb);
+  };
+  auto mma_quad = [&](auto ahc, auto bhc, const Frag<bf16_t> (&b)[2][2]) __attribute__((always_inline)) {
+    constexpr int AH = decltype(ahc)::value, BH = decltype(bhc)::value;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[AH * 4 + i][BH * 2 + j] = mma16(b[j][s], a[i][s], acc[AH * 4 + i][BH * 2 + j]);
+  };
+  auto seg_begin = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+  };
+  auto seg_end = [&]() {
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  bool tail_now = false;                              // the tile the MFMA stream is in carries the folded rows
+  {
+    int tm, tn;
+    ts.tile(0, tm, tn);
+    tail_now = args.tail_rows > 0 && tm == args.tiles_m - 1;
+  }
+  // number of this wave's vector-memory operations issued by the epilogue (stores), if the K-tile that follows is the first
+  // behind one: they sit between the prefetched parts and the parts issued from now on in the in-order counter
+  // (NST = the number EVERY wave issues at least: 16 / 32 stores; tail rows, column-sum atomics and the bias DMA only make the
+  //  wait more conservative)
+  constexpr int NST = (ACT == S4F_ACT_GELU) ? 32 : 16;
+  auto wait_parts = [&](const bool POSTEPI) __attribute__((always_inline)) {   // (wave-uniform branch around an immediate)
+    if (POSTEPI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 + NST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  };
+
+  auto ktile = [&](auto bufc, const bool POSTEPI) __attribute__((always_inline)) {
+    constexpr int BUF = decltype(bufc)::value;
+    char* cur = smem + BUF * G5_BUF;
+    char* nxt = smem + (BUF ^ 1) * G5_BUF;
+    const char* As = cur;
+    const char* Bs = cur + G5_A;
+    // phase 1: quadrant (AL, BL)
+    read_a(As, 0);
+    read_b(bl, Bs, 0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) frag_row<false>(ta[s], smem + G5_TAIL0 + BUF * G5_TAILB, 0, s);
+    fb.template issue<P_BH>(ts, nxt + G5_A);
+    wait_parts(POSTEPI);
+    seg_begin();
+    mma_quad(I0{}, I0{}, bl);
+    if (tail_now && wr == 0) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tacc[j] = mma16(bl[j][s], ta[s], tacc[j]);
+    }
+    seg_end();
+    // phase 2: quadrant (AL, BH)
+    read_b(bh, Bs, 1);
+    fa.template issue<P_AH>(ts, nxt);
+    wait_parts(POSTEPI);
+    seg_begin();
+    mma_quad(I0{}, I1{}, bh);
+    if (tail_now && wr == 1) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) tacc[j] = mma16(bh[j][s], ta[s], tacc[j]);
+    }
+    seg_end();
+    // phase 3: quadrant (AH, BH)
+    read_a(As, 1);
+    fa.template issue<P_AL>(ts, cur, smem + G5_TAIL0 + BUF * G5_TAILB);
+    wait_parts(POSTEPI);
+    seg_begin();
+    mma_quad(I1{}, I1{}, bh);
+    seg_end();
+    // phase 4: quadrant (AH, BL)
+    fb.template issue<P_BL>(ts, cur + G5_A);
+    wait_parts(POSTEPI);
+    seg_begin();
+    mma_quad(I1{}, I0{}, bl);
+    seg_end();
+  };
+
+  // ---- epilogue of tile j, in registers; leaves the accumulators at the start values of tile j + 1
+  // Output stores go through buffer resources: a row beyond M gets an out-of-range offset and the hardware drops the store, so
+  // EVERY wave issues exactly the same number of stores per tile whatever its rows are (a branch around a store that no lane
+  // needs would make the store count - which the waits behind the epilogue rely on - depend on the data).
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+  const unsigned out_bytes = (unsigned)((((long)d.M - 1) * d.ldo_t + d.N) * 2);
+  const unsigned pre_bytes = d.out_pre ? (unsigned)((((long)d.M - 1) * d.ldo_pre + d.N) * (q8 ? 1 : 2)) : 0u;
+  __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(d.out_t, 0, (int)out_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(d.out_pre ? d.out_pre : d.out_t, 0, (int)pre_bytes, 0x00020000);
+  auto epilogue = [&](int j) __attribute__((always_inline)) {
+    int tm, tn;
+    ts.tile(j, tm, tn);
+    const int m0 = tm * BM, n0 = tn * 256;
+    const int lq = opaque(l), g = lq >> 4, li = lq & 15;   // (as in acc_init)
+    bias_fetch(j + 1);
+    float cs[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[h][e] = 0.f;
+    auto put = [&](const f32x4 v0, const f32x4 v1, const int m, auto bhc) __attribute__((always_inline)) {
+      constexpr int BH = decltype(bhc)::value;
+      // the same arithmetic as the staged path of the one-tile kernel: activation on the bf16-rounded pre-activation
+      const long col = n0 + wc * 64 + BH * 32 + 8 * g;
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+      bf16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+      if constexpr (ACT == S4F_ACT_GELU) {
+        float gdv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float gy;
+          gelu_pair<false>((float)o[e], gy, gdv[e]);
+          o[e] = (bf16_t)gy;
+        }
+        if (q8) {
+          const uint2 w = gelu_d_q8x8(gdv);
+          const unsigned off = m < d.M ? (unsigned)((long)m * d.ldo_pre + col) : 0xfffffff0u;
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{w.x, w.y}, prsrc, (int)off, 0, 0);
+        } else {
+          bf16x8 pv;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pv[e] = (bf16_t)gdv[e];
+          const unsigned off = m < d.M ? (unsigned)(((long)m * d.ldo_pre + col) * 2) : 0xfffffff0u;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pv), prsrc, (int)off, 0, 0);
+        }
+      } else if constexpr (ACT == S4F_ACT_GELU_BWD) {
+        const long mm = m < d.M ? m : 0;             // rows beyond M: read row 0, stored nowhere
+        if (q8) {
+          const uint2 z = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(d.aux) + mm * d.ld_aux + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)o[e] * gelu_d_dq8_at(z, e));
+        } else {
+          const bf16x8 z = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(d.aux) + mm * d.ld_aux + col);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)o[e] * (float)z[e]);
+        }
+      }
+      {
+        const unsigned off = m < d.M ? (unsigned)(((long)m * d.ldo_t + col) * 2) : 0xfffffff0u;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), orsrc, (int)off, 0, 0);
+      }
+      if (d.colsum && m < d.M) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[BH][e] += (float)o[e];
+      }
+    };
+    static_for<8>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      put(acc[i][0], acc[i][1], m0 + wr * 128 + i * 16 + li, I0{});
+      put(acc[i][2], acc[i][3], m0 + wr * 128 + i * 16 + li, I1{});
+    });
+    if (tail_now) {
+      const int m = m0 + BM + li;
+      if (wr == 0) put(tacc[0], tacc[1], m, I0{});
+      else put(tacc[0], tacc[1], m, I1{});
+    }
+    if (d.colsum) {                                    // block-uniform: rows li of every 16-lane group, then one atomic per column
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = cs[h][e];
+          t += __shfl_xor(t, 1, 64); t += __shfl_xor(t, 2, 64); t += __shfl_xor(t, 4, 64); t += __shfl_xor(t, 8, 64);
+          if (li == e) atomicAdd(d.colsum + n0 + wc * 64 + h * 32 + 8 * g + e, t);
+        }
+    }
+  };
+
+  // ---- the K-tile stream: buffer = stream position & 1; a tile ends after nk K-tiles wherever that falls.  (Two K-tiles per
+  // loop iteration with the tile boundary behind either: choosing the buffer by a runtime branch around two copies of the
+  // K-tile made hipcc spill 95 registers inside the MFMA stream.)
+  int j = 0, kc = 0;
+  bool post = false;
+  auto boundary = [&]() __attribute__((always_inline)) -> bool {   // true: the workgroup is done
+    post = false;
+    if (++kc < nk) return false;
+    kc = 0;
+    if (DBG != 1) epilogue(j);
+    if (++j == nmine) return true;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");   // the bias DMA (older than the epilogue's stores) has landed
+    acc_init(j);
+    int tm, tn;
+    ts.tile(j, tm, tn);
+    tail_now = args.tail_rows > 0 && tm == args.tiles_m - 1;
+    post = true;                                     // the next K-tile's waits allow for the epilogue's stores
+    return false;
+  };
+  for (;;) {
+    ktile(I0{}, post);
+    if (boundary()) break;
+    ktile(I1{}, post);
+    if (boundary()) break;
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();         // undo the stagger
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the out-of-range DMAs behind the last tile still target LDS
+}
+
+int g5p_num_cus() {
+  static std::atomic<int> cus[64];
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int v = cus[dev & 63].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cus[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
+// does the persistent form take this problem?  (dense row-major operands, one T output, the epilogues of the token GEMMs)
+bool g5p_eligible(const s4f_gemm_desc& d) {
+  if (d.a_mode != S4F_OP_ROW || d.b_mode != S4F_OP_ROW || d.dtype != S4F_BF16) return false;
+  if (d.N % 256 != 0 || d.K % BK != 0 || d.splitk > 1 || d.alpha != 1.0f) return false;
+  if (!d.out_t || d.out_f32 || d.resid || d.pos || d.atomic) return false;
+  if (d.ldo_t % 8 != 0 || ((uintptr_t)d.out_t % 16) != 0) return false;
+  if ((((long)d.M - 1) * d.ldo_t + d.N) * 2 >= (1L << 31)) return false;                       // buffer-addressed stores
+  if (d.out_pre && (((long)d.M - 1) * d.ldo_pre + d.N) * 2 >= (1L << 31)) return false;
+  if (d.bias && ((uintptr_t)d.bias % 16) != 0) return false;
+  if (d.act == S4F_ACT_NONE) return d.out_pre == nullptr;
+  if (d.act == S4F_ACT_GELU) return d.out_pre != nullptr && d.ldo_pre % 8 == 0 && ((uintptr_t)d.out_pre % 16) == 0 && !d.colsum;
+  if (d.act == S4F_ACT_GELU_BWD) return d.aux != nullptr && d.ld_aux % 8 == 0 && ((uintptr_t)d.aux % 16) == 0;
+  return false;
+}
+
+template <int DBG = 0>
+int launch5p(const s4f_gemm_desc& d, hipStream_t st, int nwg) {
+  GemmArgs a;
+  a.d = d;
+  a.nk = ceil_div(d.K, BK);
+  a.nk_per_split = a.nk;
+  a.tiles_n = d.N / 256;
+  a.sk = 1;
+  a.zgroup = 0;
+  const int rem = d.M % BM;
+  if (rem > 0 && rem <= TAIL_MAX && d.M > BM) {
+    a.tiles_m = d.M / BM;
+    a.tail_rows = rem;
+  } else {
+    a.tiles_m = ceil_div(d.M, BM);
+    a.tail_rows = 0;
+  }
+  const long a_bytes = ((long)(d.M - 1) * d.lda + d.K) * 2, b_bytes = ((long)(d.N - 1) * d.ldb + d.K) * 2;
+  if (a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return -100;
+  const int nt = a.tiles_m * a.tiles_n;
+  if (nwg > nt) nwg = nt;
+  nwg &= ~7;
+  if (nwg < 8) return -100;
+  if (ceil_div(nt, nwg) + 8 > G5P_MAXT) return -100;
+  const size_t shm = (size_t)G5P_LDS;
+  static std::atomic<uint64_t> attr_set[3];
+  const int ai = d.act == S4F_ACT_GELU ? 1 : (d.act == S4F_ACT_GELU_BWD ? 2 : 0);
+  const void* kern = d.act == S4F_ACT_GELU ? (const void*)gemm5p_kernel<S4F_ACT_GELU, DBG>
+                   : d.act == S4F_ACT_GELU_BWD ? (const void*)gemm5p_kernel<S4F_ACT_GELU_BWD, DBG>
+                                               : (const void*)gemm5p_kernel<S4F_ACT_NONE, DBG>;
+  s4f_set_max_lds(attr_set[ai], kern, (int)shm);
+  if (d.act == S4F_ACT_GELU) hipLaunchKernelGGL((gemm5p_kernel<S4F_ACT_GELU, DBG>), dim3(nwg), dim3(512), shm, st, a, nwg);
+  else if (d.act == S4F_ACT_GELU_BWD) hipLaunchKernelGGL((gemm5p_kernel<S4F_ACT_GELU_BWD, DBG>), dim3(nwg), dim3(512), shm, st, a, nwg);
+  else hipLaunchKernelGGL((gemm5p_kernel<S4F_ACT_NONE, DBG>), dim3(nwg), dim3(512), shm, st, a, nwg);
+  return 0;
+}
+
 template <int AMODE, int DBG>
 __global__ __launch_bounds__(512) void gemm5_kernel(const GemmArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -559,6 +1090,18 @@ int s4f_gemm5_try(const s4f_gemm_desc& d, hipStream_t st) {
   if (d.a_mode == S4F_OP_ROW && d.tile_hint == 11) return g5::launch5<S4F_OP_ROW, 1>(d, st);
   if (d.a_mode == S4F_OP_ROW && d.tile_hint == 12) return g5::launch5<S4F_OP_ROW, 2>(d, st);
 #endif
+  // tile_hint 10: the persistent form where it applies and the launch has more than one round of tiles; 13: wherever it
+  // applies; 14: never (same-box A/B of the two forms)
+  if (d.tile_hint != 14 && g5::g5p_eligible(d)) {
+    const int cus = g5::g5p_num_cus();
+    const long nt = (long)(d.M / 256 + ((d.M % 256) > g5::TAIL_MAX || d.M < 256 ? 1 : 0)) * (d.N / 256);
+    // (measured, round 5: bias / GELU epilogues gain 4 - 6 % in the persistent form; the x gelu' epilogue with folded column
+    //  sums loses - twice the atomics per column, the aux loads behind the prefetched parts - and stays on the one-tile kernel)
+    if (d.tile_hint == 13 || (G5P_AUTO && nt > cus && d.act != S4F_ACT_GELU_BWD)) {
+      const int rc = g5::launch5p<>(d, st, cus);
+      if (rc != -100) return rc;
+    }
+  }
   if (d.a_mode == S4F_OP_ROW) return g5::launch5<S4F_OP_ROW>(d, st);
   if (d.a_mode == S4F_OP_ROW_CONV) return g5::launch5<S4F_OP_ROW_CONV>(d, st);
   return -100;

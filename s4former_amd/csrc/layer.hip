@@ -47,6 +47,7 @@ S4F_API int s4f_encoder_layer_fwd(const s4f_layer_desc* p, s4f_stream stream) {
             "s4f_encoder_layer_fwd: null tensor");
   S4F_CHECK(L.wqkv && L.wo && L.w1 && L.w2 && L.ln1_g && L.ln1_b && L.ln2_g && L.ln2_b, "s4f_encoder_layer_fwd: null parameter");
   const int M = L.B * L.N, E = L.E, F = L.F, T = L.dtype;
+  S4F_CHECK(!L.gelu_q8 || T == S4F_BF16, "s4f_encoder_layer_fwd: gelu_q8 is a bf16-mode layout");
   const bool xt = L.xdtype == S4F_BF16;            // residual stream in the operand type
   TRY(s4f_layernorm_fwd(L.x, L.ln1_g, L.ln1_b, L.xn, L.mean1, L.rstd1, M, E, M, 0, L.eps, T, L.xdtype, stream));
   {
@@ -65,7 +66,7 @@ S4F_API int s4f_encoder_layer_fwd(const s4f_layer_desc* p, s4f_stream stream) {
   {
     G g(L.xn2, L.w1, M, F, E, E, E, T);
     g.d.bias = L.b1; g.d.out_t = L.a; g.d.ldo_t = F; g.d.act = S4F_ACT_GELU; g.d.tile_hint = L.hint[2];
-    if (L.gelu_d) { g.d.out_pre = L.gelu_d; g.d.ldo_pre = F; }
+    if (L.gelu_d) { g.d.out_pre = L.gelu_d; g.d.ldo_pre = F; g.d.gelu_q8 = L.gelu_q8; }
     TRY(s4f_gemm(&g.d, stream));
   }
   {
@@ -117,7 +118,7 @@ S4F_API int s4f_encoder_layer_bwd(const s4f_layer_desc* p, s4f_stream stream, s4
   bool folded = false;
   {
     G g = dgrad(L.g2t, L.w2, L.w2_T, F, E, L.dz, L.hint[4]);
-    g.d.aux = L.gelu_d; g.d.ld_aux = F; g.d.act = S4F_ACT_GELU_BWD;
+    g.d.aux = L.gelu_d; g.d.ld_aux = F; g.d.act = S4F_ACT_GELU_BWD; g.d.gelu_q8 = L.gelu_q8;
     if (L.fold_colsum && can_fold_colsum(g.d)) { g.d.colsum = L.d_b1; folded = true; }
     TRY(s4f_gemm(&g.d, stream));
   }

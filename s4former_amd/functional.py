@@ -362,6 +362,9 @@ FUSED_LAUNCH = os.environ.get('S4F_FUSED_LAUNCH', '1') != '0'
 # workspace (the fp32 dQ slabs: 204 MB at 16 images x 1025 tokens) is ONE buffer per device shared by all layers: the backward of
 # the layers is serial on the chain's stream, and the buffer holds nothing between two calls.
 ATTN_BWD_FUSED = os.environ.get('S4F_ATTN_BWD_FUSED', '1') != '0'
+# Round 5: gelu'(z), the tensor the fc1 epilogue leaves for the backward, as 8-bit fixed point in bf16 mode (s4f_gemm_desc.gelu_q8:
+# step 1/192 = what bf16 resolves near 1): 50 MB less written by fc1 and read by the fc2 input gradient per layer (`=0`: bf16).
+GELU_Q8 = os.environ.get('S4F_GELU_Q8', '1') != '0'
 _ATTN_WS = {}
 
 
@@ -473,7 +476,7 @@ class LayerFn(Function):
         xn2 = torch.empty(M, E, device=dev, dtype=T)
         mean2 = torch.empty(M, device=dev); rstd2 = torch.empty(M, device=dev)
         # gelu'(z) is written only when a backward pass will read it (never on the teacher / inference path)
-        z = torch.empty(M, F_, device=dev, dtype=T) if need_grad else None
+        z = torch.empty(M, F_, device=dev, dtype=torch.uint8 if (GELU_Q8 and code == BF16) else T) if need_grad else None
         a = torch.empty(M, F_, device=dev, dtype=T)
         x2 = torch.empty(Bn, N, E, device=dev, dtype=R)
         plan = _layer_plan(store, prm, M, E, F_, num_heads, code, R) if (FUSED_LAUNCH and L._prof is None) else None
@@ -483,6 +486,7 @@ class LayerFn(Function):
             d.bias_u, d.row_flag = _lp(bias_u), _lp(row_flag)
             d.x, d.xn, d.mean1, d.rstd1, d.qkv, d.ctx, d.lse = x.data_ptr(), xn.data_ptr(), mean1.data_ptr(), rstd1.data_ptr(), qkv.data_ptr(), ctxv.data_ptr(), lse.data_ptr()
             d.x1, d.xn2, d.mean2, d.rstd2, d.gelu_d, d.a, d.x2 = x1.data_ptr(), xn2.data_ptr(), mean2.data_ptr(), rstd2.data_ptr(), _lp(z), a.data_ptr(), x2.data_ptr()
+            d.gelu_q8 = 1 if (z is not None and z.dtype == torch.uint8) else 0
             L.call('s4f_encoder_layer_fwd', d, L.stream())
         else:
             K.layernorm_fwd(x, store.phys(g1), store.phys(b1), xn, mean1, rstd1, M, E, code, eps)
@@ -537,6 +541,7 @@ class LayerFn(Function):
             d.bias_u, d.row_flag = _lp(sv['bias_u']), _lp(sv['row_flag'])
             d.x, d.xn, d.mean1, d.rstd1, d.qkv, d.ctx, d.lse = sv['x'].data_ptr(), xn.data_ptr(), sv['mean1'].data_ptr(), sv['rstd1'].data_ptr(), sv['qkv'].data_ptr(), ctxv.data_ptr(), sv['lse'].data_ptr()
             d.x1, d.xn2, d.mean2, d.rstd2, d.gelu_d, d.a = sv['x1'].data_ptr(), xn2.data_ptr(), sv['mean2'].data_ptr(), sv['rstd2'].data_ptr(), sv['z'].data_ptr(), a_act.data_ptr()
+            d.gelu_q8 = 1 if sv['z'].dtype == torch.uint8 else 0
             d.g2, d.g2t, d.g2cs = g2.data_ptr(), g2t.data_ptr(), _lp(g2cs)
             d.dz, d.dxn2, d.g1, d.g1t, d.dctx, d.dqkv, d.delta, d.dxn = dz.data_ptr(), dxn2.data_ptr(), g1.data_ptr(), g1t.data_ptr(), dctx.data_ptr(), dqkv.data_ptr(), delta.data_ptr(), dxn.data_ptr()
             d.g0, d.g0t, d.g0cs = g0.data_ptr(), (g0t if g0t is not None else g0).data_ptr(), g0cs.data_ptr()

@@ -172,7 +172,7 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
                              atomic, sk, conv, pos_period, pos, h)
             choice = _tune_gemm(key, run, [(h, sk) for h in hints for sk in sks])
         tile_hint, splitk = choice
-    fold = (colsum is not None and FOLD_COLSUM and tile_hint == 10 and dtype == BF16 and a_mode != OP_K and b_mode == OP_ROW and
+    fold = (colsum is not None and FOLD_COLSUM and tile_hint in (10, 13, 14) and dtype == BF16 and a_mode != OP_K and b_mode == OP_ROW and
             N % 256 == 0 and K % 64 == 0 and out_t is not None and out_f32 is None and resid is None and pos is None and
             not atomic and splitk <= 1 and (act != ACT_NONE or out_pre is None) and ldo_t % 8 == 0 and
             (out_pre is None or ldo_pre % 8 == 0) and (aux is None or ld_aux % 8 == 0))
@@ -186,7 +186,14 @@ def gemm(A, B, M, N, K, lda, ldb, dtype, a_mode=OP_ROW, b_mode=OP_ROW, *, alpha=
 def _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, resid, ldr, out_f32, ldo_f32, out_t, ldo_t,
                  out_pre, ldo_pre, aux, ld_aux, act, atomic, splitk, conv, pos_period, pos, tile_hint, colsum=None):
     _chk_dtype(A, dtype, 'gemm A'); _chk_dtype(B, dtype, 'gemm B')
-    _chk_dtype(out_t, dtype, 'gemm out_t'); _chk_dtype(out_pre, dtype, 'gemm out_pre'); _chk_dtype(aux, dtype, 'gemm aux')
+    _chk_dtype(out_t, dtype, 'gemm out_t')
+    # round 5: a uint8 gelu' tensor selects the 8-bit fixed-point layout (s4f_gemm_desc.gelu_q8; bf16 mode only)
+    gelu_q8 = any(t is not None and t.dtype == torch.uint8 for t in (out_pre, aux))
+    if gelu_q8:
+        if dtype != BF16 or act not in (ACT_GELU, ACT_GELU_BWD):
+            raise S4FError("gemm: a uint8 gelu' tensor needs bf16 mode and ACT_GELU / ACT_GELU_BWD")
+    else:
+        _chk_dtype(out_pre, dtype, 'gemm out_pre'); _chk_dtype(aux, dtype, 'gemm aux')
     _chk_f32(bias, 'gemm bias'); _chk_f32(out_f32, 'gemm out_f32'); _chk_f32(pos, 'gemm pos')
     resid_t = resid is not None and resid.dtype == torch.bfloat16
     if resid_t:
@@ -239,6 +246,7 @@ def _gemm_launch(A, B, M, N, K, lda, ldb, dtype, a_mode, b_mode, alpha, bias, re
     d.out_pre, d.ldo_pre = p(out_pre), ldo_pre
     d.aux, d.ld_aux = p(aux), ld_aux
     d.act, d.atomic = act, 1 if atomic else 0
+    d.gelu_q8 = 1 if gelu_q8 else 0
     d.pos_period, d.pos = pos_period, p(pos)
     d.tile_hint = tile_hint
     _chk_f32(colsum, 'gemm colsum')

@@ -314,11 +314,13 @@ def test_attention_fwd_q256_wide_score_range(K, N, ramp):
 
 
 @pytest.mark.parametrize('B,N,H,bias', [(2, 197, 12, 0), (1, 130, 3, 1), (2, 65, 2, 2), (1, 1025, 2, 0), (3, 300, 5, 1), (1, 2305, 1, 2),
-                                        (2, 257, 2, 2), (1, 258, 1, 1), (2, 1, 2, 0), (1, 2, 1, 1), (1, 513, 3, 2)])
+                                        (2, 257, 2, 2), (1, 258, 1, 1), (2, 1, 2, 0), (1, 2, 1, 1), (1, 513, 3, 2), (3, 1025, 12, 2)])
 def test_attention_bwd_fused(K, B, N, H, bias):
     """round 4: the one-sweep backward (five MFMA products per score tile, dQ through fp32 slabs, the cls key as a side path)
     against the oracle's autograd AND against the two-kernel form it replaces; ragged key blocks (N - 1 not a multiple of 256),
-    exactly one / two key blocks, N = 1 (no patch key at all), query slices with one row"""
+    exactly one / two key blocks, N = 1 (no patch key at all), query slices with one row.  Round 5: the slabs of a head are
+    added by the last of its key blocks to finish (release / ticket / acquire inside the launch): 36 heads x 4 blocks in flight
+    together, twice, bitwise equal"""
     code = 1
     C = H * 64
     qkv = q(rnd(B, N, 3 * C, seed=1), code)
@@ -816,6 +818,126 @@ def test_gemm2_folded_tail(K, hint, M):
     K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), resid=dev(r), ldr=N, out_f32=o4, ldo_f32=N,
            atomic=True, splitk=3, tile_hint=hint)
     check(o4, ref, code, f'folded tail split-K hint {hint} M {M}')
+
+
+@pytest.mark.parametrize('hint', [0, 1, 2, 4, 8, 10])
+@pytest.mark.parametrize('M', [2 * 1025, 256 + 17, 130])
+def test_gemm_gelu_q8(K, hint, M):
+    """round 5: gelu' as 8-bit fixed point (s4f_gemm_desc.gelu_q8; code = rint(192 g') + 25).  The fc1 epilogue must write the
+    code of the derivative AT THE bf16-ROUNDED pre-activation (what the bf16 layout stores, too) - compared code for code, one
+    step allowed where gelu' sits on a rounding boundary - and the fc2 input-gradient epilogue must multiply by the decoded
+    value exactly."""
+    code = 1
+    N, K_ = 768, 192
+    x, w, b = q(rnd(M, K_, seed=1), code), q(rnd(N, K_, seed=2, scale=0.08), code), rnd(N, seed=3)
+    out_t = torch.empty(M, N, device='cuda', dtype=tdt(code))
+    pre_ref = torch.empty(M, N, device='cuda', dtype=tdt(code))
+    pre_q8 = torch.full((M, N), 255, device='cuda', dtype=torch.uint8)
+    K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), out_t=out_t, ldo_t=N, out_pre=pre_ref, ldo_pre=N,
+           act=K.ACT_GELU, tile_hint=hint)
+    a_ref = out_t.clone()
+    K.gemm(dev(x, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(b), out_t=out_t, ldo_t=N, out_pre=pre_q8, ldo_pre=N,
+           act=K.ACT_GELU, tile_hint=hint)
+    assert torch.equal(out_t, a_ref), 'the gelu output must not depend on the layout of the derivative'
+    z = O.linear(x, w, b)
+    zr_ = z.clone().requires_grad_(True)
+    O.gelu(zr_).sum().backward()
+    dec = (pre_q8.float().cpu() - 25.0) / 192.0
+    # against the oracle's derivative of the fp32 pre-activation: the code's half step + the bf16 rounding of z
+    err = (dec - zr_.grad).abs().max().item()
+    assert err <= 1.0 / 384 + 1.2e-2, f"q8 gelu' vs oracle: {err:.3e}"
+    # against the bf16 layout of the same launch (same rounded z): half a code step + half a bf16 ulp of the bf16 value
+    err2 = (dec - pre_ref.float().cpu()).abs().max().item()
+    assert err2 <= 1.0 / 384 + 2.0 ** -8 + 1e-6, f"q8 gelu' vs the bf16 layout: {err2:.3e}"
+    assert int(pre_q8.max()) <= 242 and int(pre_q8.min()) >= 0
+    # exact points: z = 0 -> 0.5 -> code 121; z >> 0 -> 1 -> 217; z << 0 -> 0 -> 25
+    xz = torch.zeros(M, K_); bz = torch.zeros(N); bz[0::3] = 40.0; bz[1::3] = -40.0
+    K.gemm(dev(xz, code), dev(w, code), M, N, K_, K_, K_, code, bias=dev(bz), out_t=out_t, ldo_t=N, out_pre=pre_q8, ldo_pre=N,
+           act=K.ACT_GELU, tile_hint=hint)
+    want = torch.tensor([217, 25, 121], dtype=torch.uint8).repeat(N // 3).cuda().expand(M, N)
+    assert torch.equal(pre_q8, want)
+    # backward epilogue: dz = (dy w2) * decode(codes), NN against a k-major weight
+    K2 = 576
+    dy, w2 = q(rnd(M, N, seed=5), code), q(rnd(N, K2, seed=6, scale=0.05), code)
+    codes = torch.randint(0, 243, (M, K2), generator=torch.Generator().manual_seed(7), dtype=torch.uint8)
+    gp = (codes.float() - 25.0) / 192.0
+    dz = torch.empty(M, K2, device='cuda', dtype=tdt(code))
+    K.gemm(dev(dy, code), dev(w2, code), M, K2, N, N, K2, code, b_mode=K.OP_K, out_t=dz, ldo_t=K2, aux=codes.cuda(), ld_aux=K2,
+           act=K.ACT_GELU_BWD, tile_hint=hint)
+    check(dz, (dy @ w2) * gp, code, f'q8 gelu backward epilogue hint {hint} M {M}', tol=1e-2)
+    # row-major x row-major (the bf16 step's form: transposed weight shadow), N = 768 so that hint 10 takes its staged path
+    w2t = w2.t().contiguous()
+    K3 = 768
+    dy3, w3 = q(rnd(M, K_, seed=8), code), q(rnd(K3, K_, seed=9, scale=0.05), code)
+    codes3 = torch.randint(0, 243, (M, K3), generator=torch.Generator().manual_seed(10), dtype=torch.uint8)
+    dz3 = torch.empty(M, K3, device='cuda', dtype=tdt(code))
+    cs = torch.zeros(K3, device='cuda')
+    folded = K.gemm(dev(dy3, code), dev(w3, code), M, K3, K_, K_, K_, code, out_t=dz3, ldo_t=K3, aux=codes3.cuda(), ld_aux=K3,
+                    act=K.ACT_GELU_BWD, tile_hint=hint, colsum=cs)
+    ref3 = (dy3 @ w3.t()) * ((codes3.float() - 25.0) / 192.0)
+    check(dz3, ref3, code, f'q8 gelu backward epilogue (row-major B) hint {hint} M {M}', tol=1e-2)
+    if folded:
+        check(cs, dz3.float().sum(0).cpu(), 0, 'folded column sums of the q8 backward epilogue', tol=1e-4)
+    # fp32 mode refuses the layout
+    from s4former_amd.kernels import S4FError
+    with pytest.raises(S4FError):
+        K.gemm(dev(x, 0), dev(w, 0), M, N, K_, K_, K_, 0, bias=dev(b), out_t=torch.empty(M, N, device='cuda'), ldo_t=N, out_pre=pre_q8,
+               ldo_pre=N, act=K.ACT_GELU)
+
+
+@pytest.mark.parametrize('M,N,K_', [(16400, 3072, 192), (8200, 2304, 128), (2050, 768, 64), (256 + 17, 512, 320), (4100, 768, 768),
+                                    (16400, 1024, 64)])
+def test_gemm_persistent(K, M, N, K_):
+    """round 5: the persistent form of the 8-wave kernel (tile_hint 13: one workgroup per CU walks its tiles, the LDS-DMA stream
+    runs across tile boundaries, the epilogue works on the accumulators in registers - swapped MFMA operands, permuted B rows,
+    bias as the accumulators' start value) against the oracle and against the one-tile kernel (hint 14), for every epilogue it
+    takes: bias, GELU + gelu' (bf16 and 8-bit), x gelu' with folded column sums.  1 - 3 tiles per workgroup, odd / even / single
+    K-tile counts (the stream's buffer parity flips between tiles), folded tail rows, a ragged last tile row."""
+    code = 1
+    x, w, b = q(rnd(M, K_, seed=1), code), q(rnd(N, K_, seed=2, scale=0.08), code), rnd(N, seed=3)
+    xd, wd, bd = dev(x, code), dev(w, code), dev(b)
+    z = O.linear(x, w, b)
+    outs = {}
+    for hint in (13, 14):
+        o = torch.full((M, N), float('nan'), device='cuda', dtype=tdt(code))
+        K.gemm(xd, wd, M, N, K_, K_, K_, code, bias=bd, out_t=o, ldo_t=N, tile_hint=hint)
+        check(o, z, code, f'persistent gemm bias hint {hint}', tol=1e-2)
+        outs[hint] = o
+    d = (outs[13].float() - outs[14].float()).abs().max().item() / (z.abs().max().item() + 1e-30)
+    assert d <= 2.0 ** -7, f'persistent vs one-tile kernel: {d:.3e}'      # one bf16 ulp: the bias enters the sum at the other end
+    # no bias
+    o = torch.full((M, N), float('nan'), device='cuda', dtype=tdt(code))
+    K.gemm(xd, wd, M, N, K_, K_, K_, code, out_t=o, ldo_t=N, tile_hint=13)
+    check(o, x @ w.t(), code, 'persistent gemm, no bias', tol=1e-2)
+    # GELU + gelu' in both layouts
+    zr_ = z.clone().requires_grad_(True)
+    O.gelu(zr_).sum().backward()
+    for pre_dt in (tdt(code), torch.uint8):
+        o = torch.full((M, N), float('nan'), device='cuda', dtype=tdt(code))
+        pre = torch.zeros(M, N, device='cuda', dtype=pre_dt)
+        K.gemm(xd, wd, M, N, K_, K_, K_, code, bias=bd, out_t=o, ldo_t=N, out_pre=pre, ldo_pre=N, act=K.ACT_GELU, tile_hint=13)
+        check(o, O.gelu(z), code, f'persistent gelu out ({pre_dt})', tol=1.5e-2)
+        got = (pre.float().cpu() - 25.0) / 192.0 if pre_dt == torch.uint8 else pre.float().cpu()
+        err = (got - zr_.grad).abs().max().item()
+        assert err <= 1.5e-2, f"persistent gelu' ({pre_dt}): {err:.3e}"
+    # x gelu' with the column sums folded in
+    for aux_dt in (tdt(code), torch.uint8):
+        if aux_dt == torch.uint8:
+            codes = torch.randint(0, 243, (M, N), generator=torch.Generator().manual_seed(7), dtype=torch.uint8)
+            gp, aux = (codes.float() - 25.0) / 192.0, codes.cuda()
+        else:
+            gp = q(torch.rand(M, N, generator=torch.Generator().manual_seed(7)) * 1.2 - 0.1, code)
+            aux = dev(gp, code)
+        o = torch.full((M, N), float('nan'), device='cuda', dtype=tdt(code))
+        cs = torch.zeros(N, device='cuda')
+        folded = K.gemm(xd, wd, M, N, K_, K_, K_, code, out_t=o, ldo_t=N, aux=aux, ld_aux=N, act=K.ACT_GELU_BWD, colsum=cs, tile_hint=13)
+        check(o, (x @ w.t()) * gp, code, f'persistent x gelu-prime ({aux_dt})', tol=1e-2)
+        assert folded
+        check(cs, o.float().sum(0).cpu(), 0, 'persistent folded column sums', tol=2e-4)
+    # bitwise repeatable (no atomics on the output path)
+    o2 = torch.full((M, N), float('nan'), device='cuda', dtype=tdt(code))
+    K.gemm(xd, wd, M, N, K_, K_, K_, code, bias=bd, out_t=o2, ldo_t=N, tile_hint=13)
+    assert torch.equal(o2, outs[13])
 
 
 @pytest.mark.parametrize('hint', [4, 10])
