@@ -383,6 +383,11 @@ int s4f_ce_bwd(const float* logits, const int64_t* labels, const float* class_we
  * optional T shadow copy of the new teacher values. */
 int s4f_ema(float* teacher, const float* student, void* teacher_t, int64_t n, float momentum,
             float one_minus_momentum, int dtype, s4f_stream stream);
+/* round 5: the same update OUT OF PLACE: dst = fma(student, 1-m, round(teacher*m)) (+ its T shadow dst_t or NULL); teacher is
+ * only read.  With two teacher arenas the update of an arena range can run right behind that range's SGD, under the rest of the
+ * backward pass, and become the visible teacher at the head of the next forward_train (encoder_decoder.py:416-423) by a swap. */
+int s4f_ema_to(const float* teacher, const float* student, float* dst, void* dst_t, int64_t n, float momentum,
+               float one_minus_momentum, int dtype, s4f_stream stream);
 /* torch.optim.SGD(momentum, wd=0, dampening 0, nesterov False): first_step: buf = g else buf = mom*buf + g;
  * p -= lr*buf; optional T shadow of p; grad_scale multiplies g first (DDP mean). Segments with different lr
  * are separate calls on sub-ranges of the arenas.  first_step: bit 0 = first step, bit 1 (round 3) = write zeros over the

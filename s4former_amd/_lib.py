@@ -115,6 +115,7 @@ _SIGS = {
     's4f_ce_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p],
     's4f_ce_bwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p],
     's4f_ema': [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p],
+    's4f_ema_to': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_int, c_void_p],
     's4f_sgd_momentum': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int, c_int,
                          c_void_p],
 }

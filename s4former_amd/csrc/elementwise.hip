@@ -346,6 +346,28 @@ __global__ void ema_kernel(float* __restrict__ t, const float* __restrict__ s, T
   }
 }
 
+// out-of-place form (round 5, the double-buffered teacher): d = fma(s, 1 - m, round(t * m)) with t read from one arena and the
+// result (and its T shadow) written to another - the same arithmetic as ema_kernel, so the two forms agree bit for bit
+template <typename T>
+__global__ void ema_to_kernel(const float* __restrict__ t, const float* __restrict__ s, float* __restrict__ d, T* __restrict__ dt, long n,
+                              float m, float om) {
+  const long n4 = n >> 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    f32x4 tv = reinterpret_cast<const f32x4*>(t)[i];
+    const f32x4 sv = reinterpret_cast<const f32x4*>(s)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) tv[e] = __fmaf_rn(sv[e], om, __fmul_rn(tv[e], m));
+    reinterpret_cast<f32x4*>(d)[i] = tv;
+    if (dt) store4<T>(dt + 4 * i, tv);
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float v = __fmaf_rn(s[i], om, __fmul_rn(t[i], m));
+    d[i] = v;
+    if (dt) dt[i] = from_f32<T>(v);
+  }
+}
+
 template <typename T>
 __global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
                            T* __restrict__ pt, long n, float lr, float mom, float gs, int flags) {
@@ -674,6 +696,19 @@ S4F_API int s4f_add_f32(const float* a, const float* b, float* out, void* out_t,
   const int grid = grid_for(n / 4, 256);
   if (dtype == S4F_BF16) hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, out, (bf16_t*)out_t, (long)n);
   else hipLaunchKernelGGL(add_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, out, (float*)out_t, (long)n);
+  S4F_LAUNCH_CHECK();
+  return 0;
+}
+
+S4F_API int s4f_ema_to(const float* teacher, const float* student, float* dst, void* dst_t, int64_t n, float momentum,
+                       float one_minus_momentum, int dtype, s4f_stream stream) {
+  DT_CHECK("s4f_ema_to");
+  S4F_CHECK(teacher && student && dst && n > 0, "s4f_ema_to: bad args");
+  S4F_CHECK(((uintptr_t)teacher % 16) == 0 && ((uintptr_t)student % 16) == 0 && ((uintptr_t)dst % 16) == 0 && ((uintptr_t)dst_t % 8) == 0,
+            "s4f_ema_to: 16-B alignment");
+  const int grid = grid_for(n / 4 + 1, 256);
+  if (dtype == S4F_BF16) hipLaunchKernelGGL(ema_to_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, teacher, student, dst, (bf16_t*)dst_t, (long)n, momentum, one_minus_momentum);
+  else hipLaunchKernelGGL(ema_to_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, teacher, student, dst, (float*)dst_t, (long)n, momentum, one_minus_momentum);
   S4F_LAUNCH_CHECK();
   return 0;
 }

@@ -34,6 +34,12 @@ from .registry import SEGMENTORS, build_backbone, build_head, build_neck
 # bandwidth and the CUs the teacher's first GEMMs want; alone at the head of the step it costs 0.23 ms.
 EMA_OVERLAP = os.environ.get('S4F_EMA_OVERLAP', '0') != '0'
 EMA_SPLIT_LAYER = 2
+# Round 5: the double-buffered teacher.  The EMA of an arena range is computed OUT OF PLACE (s4f_ema_to) into a second teacher
+# arena right behind that range's SGD - on the optimiser's stream, under the rest of the backward pass - and becomes the visible
+# teacher by a pointer swap exactly where the reference updates it, at the head of the next forward_train
+# (encoder_decoder.py:416-423): between the steps state_dict(), evaluation and checkpoints see the teacher the reference
+# shows them; the 1.08 GB launch at the head of the chain is gone.  `=0`: the in-place launch.
+EMA_DOUBLE = os.environ.get('S4F_EMA_DOUBLE', '1') != '0'
 
 
 def add_prefix(inputs, prefix):
@@ -489,6 +495,10 @@ class EncoderDecoder(BaseSegmentor):
         arenas; the per-module signature of the reference is accepted and ignored."""
         s, t = self._student_store, self._teacher_store
         m = self.momentum_backbone if momentum is None else momentum
+        pend, self._ema_pending = self.__dict__.get('_ema_pending'), None
+        if pend is not None and momentum is None and pend == self._ema_pending_key(m):
+            t.swap()                                  # the update was computed behind the previous step's SGD: make it visible
+            return
         cut = self._ema_split()
         if not cut:
             K.ema(t.flat, s.flat, t.flat_t, t.total, m, t.dtype)
@@ -506,6 +516,52 @@ class EncoderDecoder(BaseSegmentor):
             ev = torch.cuda.Event()
             ev.record(side)
         self.backbone_ema._pre_layer_wait = (EMA_SPLIT_LAYER, ev)
+
+    # ---- the double-buffered teacher (EMA_DOUBLE): hooks called by S4FSGD on the stream of the update
+    def _ema_pending_key(self, m):
+        """what the pending update was computed from: any foreign write to the student or the teacher in between (load_state_dict,
+        a torch optimiser, an in-place edit) moves a version counter and the update is dropped for the in-place launch"""
+        s, t = self._student_store, self._teacher_store
+        return (float(m), s.generation, t.generation, s._version_sum(), t._version_sum())
+
+    def _ema_double_on(self):
+        t = self._teacher_store
+        return (EMA_DOUBLE and self.ema and t is not None and t.flat is not None and t.flat.is_cuda and not EMA_OVERLAP and
+                os.environ.get('S4F_TEACHER_GRAPH', '0') != '1')
+
+    @torch.no_grad()
+    def _ema_behind_update(self, lo, hi):
+        """student arena range [lo, hi) has just been stepped (current stream): the teacher's next value of it"""
+        if not self._ema_double_on():
+            return
+        s, t = self._student_store, self._teacher_store
+        hi = min(hi, t.total)
+        if lo >= hi:
+            return
+        t.enable_double()
+        if self.__dict__.get('_ema_cov_epoch') != getattr(s, 'step_epoch', 0):
+            self._ema_cov, self._ema_cov_epoch = [], getattr(s, 'step_epoch', 0)
+        f2, ft2 = t.other()
+        K.ema_to(t.flat[lo:hi], s.flat[lo:hi], f2[lo:hi], None if ft2 is None else ft2[lo:hi], hi - lo, self.momentum_backbone, t.dtype)
+        self._ema_cov.append((lo, hi))
+
+    @torch.no_grad()
+    def _ema_finish(self):
+        """end of optimizer.step() (its stream has joined the eager streams): the rest of the teacher arena - BatchNorm running
+        statistics, ranges stepped here - and the record that makes the next forward_train swap instead of launch"""
+        if not self._ema_double_on():
+            return
+        s, t = self._student_store, self._teacher_store
+        t.enable_double()
+        cov = sorted(self._ema_cov) if self.__dict__.get('_ema_cov_epoch') == getattr(s, 'step_epoch', 0) else []
+        self._ema_cov, self._ema_cov_epoch = [], None
+        f2, ft2 = t.other()
+        pos = 0
+        for a, b in cov + [(t.total, t.total)]:
+            if a > pos:
+                K.ema_to(t.flat[pos:a], s.flat[pos:a], f2[pos:a], None if ft2 is None else ft2[pos:a], a - pos, self.momentum_backbone, t.dtype)
+            pos = max(pos, b)
+        self._ema_pending = self._ema_pending_key(self.momentum_backbone)
 
     def _ema_split(self):
         """arena offset where the side-stream part of the EMA starts (0 = one launch on the caller's stream)"""

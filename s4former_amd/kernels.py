@@ -752,6 +752,15 @@ def ema(teacher, student, teacher_t, n, momentum, dtype):
          float(np.float32(1 - momentum)), dtype, stream())
 
 
+def ema_to(teacher, student, dst, dst_t, n, momentum, dtype):
+    """out-of-place EMA (the double-buffered teacher): dst / dst_t <- the update of `teacher` with `student`; same arithmetic as ema()"""
+    _chk_f32(teacher, 'ema_to teacher'); _chk_f32(student, 'ema_to student'); _chk_f32(dst, 'ema_to dst'); _chk_dtype(dst_t, dtype, 'ema_to dst_t')
+    _need(teacher, n, 'ema_to teacher'); _need(student, n, 'ema_to student'); _need(dst, n, 'ema_to dst')
+    _need(dst_t, n if dst_t is not None else 0, 'ema_to dst_t')
+    call('s4f_ema_to', p(teacher), p(student), p(dst), p(dst_t), n, float(np.float32(momentum)), float(np.float32(1 - momentum)), dtype,
+         stream())
+
+
 def sgd_momentum(param, grad, buf, param_t, n, lr, momentum, grad_scale, first_step, dtype, zero_grad=False):
     """zero_grad=True: the gradient range is left zeroed (the next optimizer.zero_grad() then has nothing to do)"""
     for t in (param, grad, buf):

@@ -134,6 +134,10 @@ class S4FSGD(torch.optim.Optimizer):
                 K.sgd_momentum(store.flat[lo:hi], store.grad[lo:hi], store.mom[lo:hi], pt, hi - lo, lm[0], lm[1], scale,
                                store.first_sgd_step, store.dtype, zero_grad=self.fused_zero_grad)
             store.sync_T_range(a, b)                 # the transposed operand shadows of this range, behind its update
+            hook = getattr(self.model, '_ema_behind_update', None)
+            if hook is not None:                     # round 5: the teacher's NEXT value of this range, into its second arena
+                for lo, hi, _ in pieces:
+                    hook(lo, hi)
         for lo, hi, _ in pieces:
             self._eager_done.append((lo, hi, stream))
 
@@ -169,6 +173,9 @@ class S4FSGD(torch.optim.Optimizer):
                     K.sgd_momentum(store.flat[e.off:e.off + n], store.grad[e.off:e.off + n], store.mom[e.off:e.off + n], pt,
                                    n, g['lr'], g['momentum'], grad_scale, first, store.dtype, zero_grad=self.fused_zero_grad)
         store.first_sgd_step = False
+        fin = getattr(self.model, '_ema_finish', None)
+        if fin is not None:
+            fin()                                    # what the eager ranges did not cover (running statistics, ranges stepped here)
         # every parameter range of the plan has been consumed and zeroed; the flag may only be raised if the plan really covers every
         # trainable parameter of the arena (a gradient outside it would survive the skipped zero_grad() and accumulate silently)
         store.grad_clean = bool(self.fused_zero_grad) and self._plan_covers_all_params(store, plan)

@@ -26,7 +26,7 @@ def _is_conv3x3(t):
 
 class _Entry:
     __slots__ = ('module', 'attr', 'is_param', 'name', 'group', 'shape', 'numel', 'off', 'cl', 'v_phys', 'v_grad', 'v_shadow',
-                 'v_T')
+                 'v_T', 'v_log', 'alt')
 
 
 # A/B switch (round 4): hand a parameter group's pending spans to the reducer as soon as its last range is final
@@ -128,6 +128,7 @@ class ParamStore:
             src = self.flat_t if self.flat_t is not None else flat
             e.v_shadow = src[e.off:e.off + e.numel]
         self.generation = getattr(self, 'generation', 0) + 1
+        self._alt = None             # (flat, flat_t) of the second arena pair (enable_double)
         self.flat_T = None           # transposed bf16 shadows (same offsets as flat_t), allocated on first use
         self._T_items = {}           # entry offset -> (R, T, C)
         self._T_table = None         # (device int64 table, host item list)
@@ -137,6 +138,36 @@ class ParamStore:
         self._versions = None
         self.first_sgd_step = True
         return self
+
+    # ------------------------------------------------------------------ second arena pair (round 5: the double-buffered teacher)
+    def enable_double(self):
+        """allocate a second (fp32, T shadow) arena pair of the same layout and the views of every entry in it.  swap() then
+        makes it the arena the modules' parameters / buffers, phys() and shadow() point into - a pointer flip per entry, no copy."""
+        if self._alt is not None:
+            return
+        flat2 = torch.empty_like(self.flat)
+        flat_t2 = torch.empty_like(self.flat_t) if self.flat_t is not None else None
+        self._alt = (flat2, flat_t2)
+        for e in self.entries:
+            e.v_log = self._view(self.flat, e)
+            src2 = flat_t2 if flat_t2 is not None else flat2
+            e.alt = (flat2[e.off:e.off + e.numel], src2[e.off:e.off + e.numel], self._view(flat2, e))
+
+    def other(self):
+        """(flat, flat_t) of the arena pair that is NOT visible"""
+        return self._alt
+
+    def swap(self):
+        if self.with_grad or self._alt is None:
+            raise S4FError('swap() needs enable_double() on a store without gradients (the teacher)')
+        flat2, flat_t2 = self._alt
+        self._alt = (self.flat, self.flat_t)
+        self.flat, self.flat_t = flat2, flat_t2
+        for e in self.entries:
+            p2, s2, l2 = e.alt
+            e.alt = (e.v_phys, e.v_shadow, e.v_log)
+            e.v_phys, e.v_shadow, e.v_log = p2, s2, l2
+            self._tensor(e).data = l2               # same tensor objects (ids, caches keyed by them, versions): only the storage moves
 
     def is_valid(self, device):
         if self.flat is None or self.flat.device != torch.device(device):

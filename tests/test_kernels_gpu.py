@@ -724,6 +724,13 @@ def test_ema_sgd(K, code):
         K.ema(td, sd, tt, n, 0.999, code)
     check(td, ref, 0, 'ema', tol=2e-7)
     assert torch.equal(tt.cpu(), td.cpu().to(tdt(code)))
+    # round 5: the out-of-place form (double-buffered teacher) gives the same bits and leaves its source alone
+    src = dev(t.clone()); keep = src.clone()
+    dst = torch.full((n,), float('nan'), device='cuda'); dst_t = torch.empty(n, device='cuda', dtype=tdt(code))
+    one = dev(t.clone()); one_t = torch.empty(n, device='cuda', dtype=tdt(code))
+    K.ema(one, sd, one_t, n, 0.999, code)
+    K.ema_to(src, sd, dst, dst_t, n, 0.999, code)
+    assert torch.equal(dst, one) and torch.equal(dst_t, one_t) and torch.equal(src, keep)
     # SGD momentum vs torch.optim.SGD, two lr groups emulated by two calls
     p = torch.nn.Parameter(rnd(n, seed=3))
     opt = torch.optim.SGD([p], lr=0.01, momentum=0.9, weight_decay=0.0)

@@ -510,3 +510,66 @@ def test_ema_on_the_side_stream_gives_the_same_teacher(monkeypatch):
     # fp32 parity mode: the teacher pass has no atomics - equal weights give equal logits, bit for bit
     assert torch.equal(res[True][2], res[False][2]), float((res[True][2] - res[False][2]).abs().max())
     assert torch.equal(res[True][1], res[False][1])
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+def test_double_buffered_teacher_shows_the_reference_teacher(dtype, monkeypatch):
+    """round 5: the EMA is computed out of place behind the SGD of each arena range (s4f_ema_to, into a second teacher arena) and
+    becomes visible by a swap at the head of the next forward_train.  At every point a caller can look - after optimizer.step(),
+    after forward_train - the visible teacher (arena, state_dict, bf16 shadow) must be bit for bit what the in-place launch of
+    the reference's schedule (encoder_decoder.py:416-423) gives: unchanged by step(), updated with the post-step student at the
+    head of the next forward_train.  A foreign write between the steps drops the pending update."""
+    from s4former_amd import encoder_decoder as ED
+    from s4former_amd import kernels as K
+    monkeypatch.setattr(ED, 'EMA_DOUBLE', True)
+    z, meta = load_gold('mt_pasa')
+    model, opt, sched = build_product(meta, dtype)
+    run_product(model, opt, sched, meta, iters=1)                    # step 0: nothing pending yet -> the in-place launch
+    s, t = model.student_store, model.teacher_store
+    assert model.__dict__.get('_ema_pending') is not None, 'optimizer.step() did not prepare the next teacher'
+    m = model.momentum_backbone
+    swaps = 0
+    for it in range(1, 4):
+        vis = t.flat.clone()
+        stu = s.flat[:t.total].clone()
+        want = vis.clone()
+        want_t = torch.empty(t.total, device='cuda', dtype=torch.bfloat16) if t.flat_t is not None else None
+        K.ema(want, stu, want_t, t.total, m, t.dtype)                 # what the reference's in-place update makes of them
+        if it == 2:                                                   # a foreign write: the pending update must not be used
+            with torch.no_grad():
+                model.backbone.cls_token.add_(0.25)
+            stu = s.flat[:t.total].clone()
+            want = vis.clone()
+            K.ema(want, stu, want_t, t.total, m, t.dtype)
+        ptr0 = t.flat.data_ptr()
+        imgs, gt, metas = C.make_batch(meta['seed_b'] + it, meta['n_sup'], meta['n_unsup'])
+        sched.step(it)
+        opt.zero_grad()
+        C.seed_host_rng(meta['seed_b'] + it)
+        out = model.train_step(dict(img=imgs.cuda(), img_metas=metas, gt_semantic_seg=gt.cuda()), opt, iter=it)
+        torch.cuda.synchronize()
+        swaps += int(t.flat.data_ptr() != ptr0)
+        assert (t.flat.data_ptr() != ptr0) == (it != 2), 'swap expected except behind the foreign write'
+        assert torch.equal(t.flat, want), f'visible teacher after forward_train {it}: max diff {float((t.flat - want).abs().max()):.3e}'
+        if want_t is not None:
+            assert torch.equal(t.flat_t, want_t), 'bf16 shadow of the visible teacher'
+        sd = model.state_dict()
+        k0 = 'backbone_ema.layers.0.attn.attn.in_proj_weight'
+        e = t.entry(model.backbone_ema.layers[0].attn.attn.in_proj_weight)
+        assert torch.equal(sd[k0].reshape(-1), want[e.off:e.off + e.numel]), 'state_dict() must show the visible arena'
+        out['loss'].backward()
+        opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(t.flat, want), 'optimizer.step() must not change the visible teacher'
+        assert model.__dict__.get('_ema_pending') is not None
+    assert swaps == 2
+    # and the whole thing against a run with the in-place launch: same losses (the teacher passes saw the same weights)
+    monkeypatch.setattr(ED, 'EMA_DOUBLE', False)
+    model2, opt2, sched2 = build_product(meta, dtype)
+    rec2 = run_product(model2, opt2, sched2, meta, iters=2)
+    monkeypatch.setattr(ED, 'EMA_DOUBLE', True)
+    model3, opt3, sched3 = build_product(meta, dtype)
+    rec3 = run_product(model3, opt3, sched3, meta, iters=2)
+    rtol = 2e-5 if dtype == 'fp32' else 1e-3          # (bf16: run-to-run differences of the split-K atomics, amplified by bf16 rounding)
+    for k, v in rec2[1]['log'].items():
+        assert abs(rec3[1]['log'][k] - v) <= rtol * abs(v) + 1e-7, (k, rec3[1]['log'][k], v)
