@@ -636,7 +636,8 @@ struct DFeeder {
   // part PART of the part's next K-tile into the image at img (A / AL: + the folded tail rows into timg)
   template <int PART>
   __device__ __forceinline__ void issue(const TileSeq& ts, char* img, char* timg = nullptr) {
-    if (kp[PART] == nk) {                            // wave-uniform: the part moves on to the workgroup's next tile
+    // (marked unlikely: the hot path of an issue is straight-line code, the cold block is laid out behind it)
+    if (__builtin_expect(kp[PART] == nk, 0)) {       // wave-uniform: the part moves on to the workgroup's next tile
       kp[PART] = 0;
       ++jp[PART];
       set_tile<PART>(ts, jp[PART]);
@@ -791,7 +792,7 @@ __global__ __launch_bounds__(512) void gemm5p_kernel(const GemmArgs args, const 
   //  wait more conservative)
   constexpr int NST = (ACT == S4F_ACT_GELU) ? 32 : 16;
   auto wait_parts = [&](const bool POSTEPI) __attribute__((always_inline)) {   // (wave-uniform branch around an immediate)
-    if (POSTEPI) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 + NST) : "memory");
+    if (__builtin_expect(POSTEPI, 0)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(9 + NST) : "memory");
     else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   };
 
