@@ -173,8 +173,19 @@ def setup_data_parallel(model, optimizer, device, reducer=None):
         # Round 3 wrapped it in a model of the queue pattern with a self-check that never passed; round 4 first deleted both and
         # lost 2 ms at N > 1, then restored the order alone: no model, no claim about who shares a queue, and the reducer keeps a
         # communication stream of its own.
-        from .functional import pretouch_streams
+        from .functional import check_stream_layout, pretouch_streams
         pretouch_streams(device, ['decode', 'aux', 'burn', 'burn', 'side'])
+        # Round 5: what the order is FOR is measured, once, right here (a few hundred microseconds): do the chain's stream, the two
+        # head streams, the weight-gradient stream and the reducer's stream run concurrently pair by pair?  The result rides on
+        # the reducer (bench.py prints it, tests/test_zz_dist_gpu.py reads it); a runtime on which the incantation has stopped
+        # working shows up as a warning and a slower - never a wrong - step.
+        reducer.stream_layout = check_stream_layout(device, extra=[('comm', getattr(reducer, '_stream', None))])
+        if not reducer.stream_layout.get('ok'):
+            import warnings
+            bad = {k: v for k, v in reducer.stream_layout.get('pairs', {}).items() if v >= 1.5}
+            warnings.warn('s4former_amd.dist: the first-use stream order did not separate these stream pairs onto different hardware '
+                          f'queues (ratio of a pair of spin kernels to one: {bad or reducer.stream_layout}); the step is correct but '
+                          'streams that share a queue serialise (S4F_STREAM_ORDER=0 skips the pre-touch)', RuntimeWarning)
     if os.environ.get('S4F_EAGER_SGD', '1') != '0':
         # parameter ranges are updated as soon as their (all-reduced) gradient is final, behind the rest of backward
         optimizer.attach_eager(model.student_store, reducer if collectives_active() else None, reducer.grad_scale())

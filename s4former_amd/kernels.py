@@ -430,7 +430,7 @@ def attention_fwd(qkv, ctx, lse, B, N, H, dtype, bias_u=None, row_flag=None, bia
     _need(qkv, B * N * 3 * H * 64, 'attn qkv'); _need(ctx, B * N * H * 64, 'attn ctx'); _need(lse, B * H * N, 'attn lse')
     _need(bias_u, B * N if bias_u is not None else 0, 'attn bias_u')
     _need(row_flag, B * N if row_flag is not None else 0, 'attn row_flag')
-    call('s4f_attention_fwd', p(qkv), p(ctx), p(lse), p(bias_u), p(row_flag), bias_w, B, N, H, dtype, stream())
+    call('s4f_attention_fwd', p(qkv), p(ctx), p(lse), p(bias_u), p(row_flag), bias_w, B, N, H, dtype, stream(), tag=('attn', B, N, H))
 
 
 def attention_fwd_q256(qkv, ctx, lse, B, N, H, bias_u=None, row_flag=None, bias_w=0.0):
@@ -440,7 +440,7 @@ def attention_fwd_q256(qkv, ctx, lse, B, N, H, bias_u=None, row_flag=None, bias_
     _need(qkv, B * N * 3 * H * 64, 'attn qkv'); _need(ctx, B * N * H * 64, 'attn ctx'); _need(lse, B * H * N, 'attn lse')
     _need(bias_u, B * N if bias_u is not None else 0, 'attn bias_u')
     _need(row_flag, B * N if row_flag is not None else 0, 'attn row_flag')
-    call('s4f_attention_fwd_q256', p(qkv), p(ctx), p(lse), p(bias_u), p(row_flag), bias_w, B, N, H, stream())
+    call('s4f_attention_fwd_q256', p(qkv), p(ctx), p(lse), p(bias_u), p(row_flag), bias_w, B, N, H, stream(), tag=('attn', B, N, H))
 
 
 def attention_bwd(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, dtype, bias_u=None, row_flag=None, bias_w=0.0):
@@ -454,7 +454,7 @@ def attention_bwd(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, dtype, bias_u=None,
     _need(bias_u, B * N if bias_u is not None else 0, 'attn_bwd bias_u')
     _need(row_flag, B * N if row_flag is not None else 0, 'attn_bwd row_flag')
     call('s4f_attention_bwd', p(qkv), p(ctx), p(dctx), p(lse), p(delta), p(dqkv), p(bias_u), p(row_flag), bias_w, B, N,
-         H, dtype, stream())
+         H, dtype, stream(), tag=('attn', B, N, H))
 
 
 def attention_bwd_ws_bytes(B, N, H):
@@ -474,7 +474,7 @@ def attention_bwd_fused(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, ws, bias_u=No
     _need(row_flag, B * N if row_flag is not None else 0, 'attn_bwd_fused row_flag')
     nbytes = ws.numel() * ws.element_size()
     call('s4f_attention_bwd_fused', p(qkv), p(ctx), p(dctx), p(lse), p(delta), p(dqkv), p(bias_u), p(row_flag), bias_w, B, N,
-         H, p(ws), nbytes, stream())
+         H, p(ws), nbytes, stream(), tag=('attn', B, N, H))
 
 
 def bn_stats(x, rows, C, sums, dtype):

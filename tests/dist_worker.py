@@ -132,6 +132,7 @@ def main():
     rec['mom_sha'] = np.array(hashlib.sha256(model.student_store.mom.cpu().numpy().tobytes()).hexdigest())
     rec['nbt'] = np.array([int(v) for k, v in sd.items() if k.endswith('num_batches_tracked')])
     rec['issued'] = np.array([issued['grad'], issued['bn']])
+    rec['stream_layout'] = np.array(json.dumps(getattr(reducer, 'stream_layout', None)))
     rec['meta'] = np.array(json.dumps(dict(world=world, rank=rank, backend=dist.get_backend() if dist.is_initialized() else None,
                                            env={k: v for k, v in os.environ.items() if k.startswith('S4F_')})))
     np.savez(os.path.join(args.out, f'rank{rank}.npz'), **rec)

@@ -180,6 +180,10 @@ def test_one_rank_rccl_group_runs_the_data_path(single, tmp_path):
     assert r.returncode == 0, f'rc {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-4000:]}\n{_dumps(d)}'
     got, ref = _load(d, 0), single['plain']
     assert json.loads(str(got['meta']))['backend'] == 'nccl'
+    # round 5: the first-use stream order is MEASURED at set-up (pairwise concurrency of the package's streams): the record must
+    # be there and complete; whether every pair came apart is this runtime's business (a warning, not an error)
+    lay = json.loads(str(got['stream_layout']))
+    assert lay is not None and 'error' not in lay and len(lay['pairs']) >= 6 and isinstance(lay['ok'], bool), lay
     n_grad, n_bn = (int(v) for v in got['issued'])
     assert n_grad >= 2 * 4 and n_bn >= 2 * 10, (n_grad, n_bn)       # per step: >= one range per encoder layer, >= one exchange per BN call
     # (two processes: the fp32 atomics of the split-K sums differ in their last bits from run to run - the bounds of the
@@ -202,4 +206,5 @@ def test_bench_two_ranks_gloo(tmp_path):
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['value'] > 0 and out['roofline'] is not None
     assert out['config']['dist_backend'] == 'gloo' and out['config']['ranks_seen'] == 2
+    assert 'pairs' in (out['config']['stream_layout'] or {}), out['config']
     assert abs(out['losses']['loss']) < 1e3
