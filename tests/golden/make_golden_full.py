@@ -7,6 +7,7 @@
   full_sup8   8 labelled images, one iteration (BASELINE cfg2 at its real batch; no fp64 evaluation)
   full_semi8  8 + 8 images with PASA, one iteration (BASELINE cfg3 / cfg4 per GPU at its real batch; no fp64 evaluation)
   full_semi8_fwd  8 + 8 images with PASA, forward only (round 4: what fits of cfg3 at its real batch)
+  full_768_semi4_fwd  768x768, 19 classes, 4 + 4 images with PASA, forward only (round 5: cfg5 at its real per-GPU batch)
 
 Per scenario: every named loss, the total, per-parameter gradient L2 norms, 32 strided gradient elements of EVERY parameter
 (+ the tensor's max |g|), |.|_1 of every state-dict tensor after the optimiser steps (student, BN statistics, EMA teacher),
@@ -53,8 +54,11 @@ SCENARIOS = {
     # step with its backward needs ~67 GB in a 62 GB container; the forward pins all seven losses, mask_ratio and the teacher's
     # labels (+ tie set) at the batch the bench line is measured on
     'full_semi8_fwd': (512, 21, PASA, 8, 8, 0.001, 0),
+    # round 5: cfg5 (Cityscapes crops: 768 x 768, 19 classes, 2305 tokens) at its REAL per-GPU batch of 4 + 4, forward only
+    # (full_768 is 1 + 1 with its backward)
+    'full_768_semi4_fwd': (768, 19, PASA, 4, 4, 0.001, 0),
 }
-NO_FP64 = {'full_sup8', 'full_semi8', 'full_semi4', 'full_semi8_fwd'}
+NO_FP64 = {'full_sup8', 'full_semi8', 'full_semi4', 'full_semi8_fwd', 'full_768_semi4_fwd'}
 SEED_W, SEED_B, NS = 1999, 3030, 32
 FRAG = 1e-3          # the stored tie set covers every logit bound up to FRAG * max |logit|
 

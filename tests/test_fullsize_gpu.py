@@ -134,7 +134,9 @@ import numpy as np  # noqa: E402
 
 GOLD = os.path.join(ROOT, 'tests', 'golden')
 TOL = {   # (loss it0, loss it1, grad-norm it0, it1, grad-element it0, it1, final |.|_1, logit bound for the tie set)
-    'fp32': (1e-4, 1e-3, 2e-3, 5e-3, 1e-4, 5e-2, 2e-4, 2e-5),
+    # fp32 (round 5): <= 3 x the values measured at DeiT-B size (profiles/r04_parity_report.json): losses 5e-6 / 9e-6 (the first
+    # iteration keeps north_star's own 1e-4), gradient norms <= 3.9e-4 over every fixture and both iterations
+    'fp32': (1e-4, 3e-5, 1.2e-3, 1.2e-3, 1e-4, 5e-2, 2e-4, 2e-5),
     # bf16 (round 3): <= 3 x the values measured at DeiT-B size with the bf16 residual stream (profiles/r03_parity_report.json):
     # losses 6.1e-3 / 8.5e-4, gradient norms 1.8e-2 / 1.9e-2, gradient elements 90th percentile 8.8e-2 (bound 0.25; the worst
     # tensor, measured 0.17, may reach 3 x that; the median, measured 5.1e-2, is held to 0.1), pseudo-labels 1.26 % differ (3.5 %)
@@ -190,7 +192,8 @@ def _golden_run(name, dtype):
 
 
 @pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
-@pytest.mark.parametrize('name', ['full_sup', 'full_pasa', 'full_768', 'full_ours', 'full_sup8', 'full_semi4', 'full_semi8_fwd'])
+@pytest.mark.parametrize('name', ['full_sup', 'full_pasa', 'full_768', 'full_ours', 'full_sup8', 'full_semi4', 'full_semi8_fwd',
+                                  'full_768_semi4_fwd'])
 def test_fullsize_step_vs_reference_golden(name, dtype, monkeypatch):
     import s4former_amd as S
     from tests import common as C
