@@ -168,13 +168,6 @@ int s4f_add_f32(const float* a, const float* b, float* out, void* out_t, int64_t
  * bias_u / row_flag: fp32 [B, N] or NULL (PASA rank-1 mask, vit.py:519-535). */
 int s4f_attention_fwd(const void* qkv, void* ctx, float* lse, const float* bias_u, const float* row_flag,
                       float bias_w, int B, int N, int H, int dtype, s4f_stream stream);
-/* Round 4: the bf16 forward as 256-query workgroups with one wave per SIMD (scores with the QUERY on the lane, O^T in the
- * accumulator half, K / V stages by LDS-DMA, the PASA bias as a fifth contraction step, the first key tile's maximum as the fixed
- * reference point of the exponentials with an exact running-maximum sweep for rows that leave its range).  Same arguments and
- * results as s4f_attention_fwd with dtype = S4F_BF16; 64 < N <= 2560.  s4f_attention_fwd itself picks this form where it was
- * measured ahead (no bias, grids that fill their last round of CUs; S4F_ATTN_FWD3=1 / 0 forces / forbids it). */
-int s4f_attention_fwd_q256(const void* qkv, void* ctx, float* lse, const float* bias_u, const float* row_flag,
-                           float bias_w, int B, int N, int H, s4f_stream stream);
 /* delta fp32 [B,H,N] workspace; dqkv T [B,N,3*H*64] fully overwritten. */
 int s4f_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta,
                       void* dqkv, const float* bias_u, const float* row_flag, float bias_w, int B, int N, int H,

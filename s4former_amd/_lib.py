@@ -78,7 +78,6 @@ _SIGS = {
     's4f_add_f32': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p],
     's4f_attention_fwd': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int,
                           c_void_p],
-    's4f_attention_fwd_q256': [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_void_p],
     's4f_attention_bwd': [c_void_p] * 8 + [c_float, c_int, c_int, c_int, c_int, c_void_p],
     's4f_attention_bwd_fused': [c_void_p] * 8 + [c_float, c_int, c_int, c_int, c_void_p, c_int64, c_void_p],
     's4f_attention_bwd_ws_bytes': [c_int, c_int, c_int],

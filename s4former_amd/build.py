@@ -13,7 +13,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, 'csrc')
 OBJ_DIR = os.path.join(CSRC, '_obj')
 LIB_PATH = os.environ.get('S4F_LIB_OUT') or os.path.join(PKG_DIR, 'libs4f_hip.so')      # S4F_LIB_OUT: experiment builds beside the shipped one
-SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm5.hip', 'gemm6.hip', 'attention.hip', 'attn_bwd.hip', 'attn_fwd.hip', 'elementwise.hip', 'head.hip', 'eval.hip', 'pipeline.hip', 'layer.hip']
+SOURCES = ['gemm.hip', 'gemm2.hip', 'gemm5.hip', 'gemm6.hip', 'attention.hip', 'attn_bwd.hip', 'elementwise.hip', 'head.hip', 'eval.hip', 'pipeline.hip', 'layer.hip']
 HEADERS = ['common.h', os.path.join('..', '..', 'include', 's4f.h')]
 BASE_FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-ffp-contract=off',
               '-Wno-unused-result', '-Wno-unused-value']
@@ -22,20 +22,15 @@ FILE_FLAGS = {}      # per-file overrides
 # attn_bwd.hip: no SLP packing of the per-score fp32 work (v_pk_mul_f32 + the moves that pair its operands cost more issue
 # cycles beside MFMAs than two scalar multiplies: MI355X_MICROARCH, 'price of one filler beside MFMAs')
 FILE_FLAGS['attn_bwd.hip'] = FLAGS + ['-fno-slp-vectorize']
-FILE_FLAGS['attn_fwd.hip'] = FLAGS + ['-fno-slp-vectorize']
 if os.environ.get('S4F_FB_STAMPS'):   # diagnostic: s_memtime stamps around the pipeline pieces (tools/exp/fb_stamps.py)
     FILE_FLAGS['attn_bwd.hip'] = FILE_FLAGS['attn_bwd.hip'] + ['-DFB_STAMPS']
-if os.environ.get('S4F_FF_STAMPS'):
-    FILE_FLAGS['attn_fwd.hip'] = FILE_FLAGS['attn_fwd.hip'] + ['-DFF_STAMPS']
-if os.environ.get('S4F_FF_ABL'):      # ablation builds of the attention forward (timing only)
-    FILE_FLAGS['attn_fwd.hip'] = FILE_FLAGS['attn_fwd.hip'] + ['-DFF_ABL=' + os.environ['S4F_FF_ABL']]
 if os.environ.get('S4F_FB_ABL'):      # ablation builds of the one-sweep attention backward (tools/exp/fb_ablate.sh)
     FILE_FLAGS['attn_bwd.hip'] = FILE_FLAGS['attn_bwd.hip'] + ['-DFB_ABL=' + os.environ['S4F_FB_ABL']]
 if os.environ.get('S4F_G5P_AUTO'):    # A/B build: S4F_G5P_AUTO=0 keeps tile_hint 10 on the one-tile kernel
     FILE_FLAGS['gemm5.hip'] = FILE_FLAGS.get('gemm5.hip', FLAGS) + ['-DG5P_AUTO=' + os.environ['S4F_G5P_AUTO']]
 if os.environ.get('S4F_G5_PROBES'):
     FILE_FLAGS['gemm5.hip'] = FILE_FLAGS.get('gemm5.hip', FLAGS) + ['-DG5_PROBES']
-_DIAG = [v for v in ('S4F_FB_STAMPS', 'S4F_FF_STAMPS', 'S4F_FF_ABL', 'S4F_FB_ABL', 'S4F_G5_PROBES', 'S4F_G5P_AUTO') if os.environ.get(v)]
+_DIAG = [v for v in ('S4F_FB_STAMPS', 'S4F_FB_ABL', 'S4F_G5_PROBES', 'S4F_G5P_AUTO') if os.environ.get(v)]
 if _DIAG and not os.environ.get('S4F_LIB_OUT'):
     # stamp / ablation builds compute wrong results by construction: they never overwrite the shipped library
     raise RuntimeError(f'{", ".join(_DIAG)} select a diagnostic build: set S4F_LIB_OUT=<path of the experiment library> as well')

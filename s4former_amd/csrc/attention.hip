@@ -951,8 +951,6 @@ static int attn_nw() {
 
 }  // namespace
 
-int s4f_attention_fwd3_try(const void* qkv, void* ctx, float* lse, const float* bias_u, const float* row_flag, float bias_w,
-                           int B, int N, int H, hipStream_t st);     // attn_fwd.hip (round 4)
 
 S4F_API int s4f_attention_fwd(const void* qkv, void* ctx, float* lse, const float* bias_u, const float* row_flag,
                               float bias_w, int B, int N, int H, int dtype, s4f_stream stream) {
@@ -966,19 +964,6 @@ S4F_API int s4f_attention_fwd(const void* qkv, void* ctx, float* lse, const floa
   const int nw = attn_nw();
   hipStream_t st = (hipStream_t)stream;
   if (dtype == S4F_BF16) {
-    // attn_fwd.hip (round 4; 256-query blocks, one wave per SIMD) where it was measured ahead of attn_fwd2: no bias and a grid
-    // that fills its last round of 256 CUs to 80 % (DESIGN A.14: 79 vs 87 us at B = 16, N = 1025; behind at B = 8 (384 blocks)
-    // and with the bias: 101 vs 96 us).  S4F_ATTN_FWD3=1 forces it wherever it applies, =0 turns it off.
-    static const int fwd3 = [] { const char* e = getenv("S4F_ATTN_FWD3"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
-    bool use3 = fwd3 == 1;
-    if (fwd3 == -1 && !bias_u) {
-      const long blocks = (long)((N % 256 == 1) ? N / 256 : (N + 255) / 256) * H * B;
-      use3 = blocks > 0 && 5 * blocks >= 4 * ((blocks + 255) / 256) * 256;
-    }
-    if (use3 && s4f_attention_fwd3_try(qkv, ctx, lse, bias_u, row_flag, bias_w, B, N, H, st) == 0) {
-      S4F_LAUNCH_CHECK();
-      return 0;
-    }
     static const bool diet = [] { const char* e = getenv("S4F_ATTN_FWD2"); return !e || atoi(e) != 0; }();
     if (diet) {
       a.nblk = ceil_div(a.N, 128);

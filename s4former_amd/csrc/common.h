@@ -211,6 +211,12 @@ static inline void s4f_set_max_lds(std::atomic<uint64_t>& mask, const void* kern
   (void)hipGetDevice(&dev);
   const uint64_t bit = 1ull << (dev & 63);
   if (mask.load(std::memory_order_acquire) & bit) return;
-  (void)hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  // (the bit is set only on success: a failed call is repeated - and reported through s4f_last_error() - at every launch, whose
+  //  own failure S4F_LAUNCH_CHECK then returns, instead of surfacing once as an opaque launch error)
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    snprintf(s4f_err_buf, sizeof(s4f_err_buf), "hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d) failed: %s", bytes, hipGetErrorString(e));
+    return;
+  }
   mask.fetch_or(bit, std::memory_order_release);
 }

@@ -370,7 +370,9 @@ _ATTN_WS = {}
 
 def _attn_bwd_ws(Bn, N, H, device):
     need = K.attention_bwd_ws_bytes(Bn, N, H)
-    key = (device.type, device.index)
+    # one workspace per (device, STREAM): the buffer holds nothing between two calls, but two backward passes enqueued on different
+    # streams (a second model, a backward under a head stream) would race on the dQ slabs of a shared one
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _ATTN_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=device, dtype=torch.uint8)
@@ -959,7 +961,11 @@ class TapSplitFn(Function):
                 for ev in evs:
                     cur.wait_event(ev)
                 if g is not None and g.data_ptr() != buf[a:b].data_ptr():
-                    buf[a:b].add_(g)                 # a consumer outside the protocol besides the heads
+                    # a consumer outside the protocol BESIDES heads that wrote in place: autograd has summed their view of buf with
+                    # the other gradient out of place, so g already contains buf's rows - adding it would count the heads twice,
+                    # copying it would be right only if every head had finished before autograd summed.  Not a case the step has.
+                    raise S4FError('TapSplitFn: a tap part feeds both a head (in-place gradient) and another consumer; route the '
+                                   'other consumer through its own part or set S4F_TAP_SPLIT=0')
             rows.update(range(a, b))
             ready.append((a, b))
         h.buf = None

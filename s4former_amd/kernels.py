@@ -433,16 +433,6 @@ def attention_fwd(qkv, ctx, lse, B, N, H, dtype, bias_u=None, row_flag=None, bia
     call('s4f_attention_fwd', p(qkv), p(ctx), p(lse), p(bias_u), p(row_flag), bias_w, B, N, H, dtype, stream(), tag=('attn', B, N, H))
 
 
-def attention_fwd_q256(qkv, ctx, lse, B, N, H, bias_u=None, row_flag=None, bias_w=0.0):
-    """the round-4 bf16 forward called directly (s4f_attention_fwd dispatches to it where it is the faster form)"""
-    _chk_dtype(qkv, 1, 'attn qkv'); _chk_dtype(ctx, 1, 'attn ctx'); _chk_f32(lse, 'attn lse')
-    _chk_f32(bias_u, 'attn bias_u'); _chk_f32(row_flag, 'attn row_flag')
-    _need(qkv, B * N * 3 * H * 64, 'attn qkv'); _need(ctx, B * N * H * 64, 'attn ctx'); _need(lse, B * H * N, 'attn lse')
-    _need(bias_u, B * N if bias_u is not None else 0, 'attn bias_u')
-    _need(row_flag, B * N if row_flag is not None else 0, 'attn row_flag')
-    call('s4f_attention_fwd_q256', p(qkv), p(ctx), p(lse), p(bias_u), p(row_flag), bias_w, B, N, H, stream(), tag=('attn', B, N, H))
-
-
 def attention_bwd(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, dtype, bias_u=None, row_flag=None, bias_w=0.0):
     for t, w in ((qkv, 'qkv'), (ctx, 'ctx'), (dctx, 'dctx'), (dqkv, 'dqkv')):
         _chk_dtype(t, dtype, 'attn_bwd ' + w)

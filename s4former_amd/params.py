@@ -372,6 +372,9 @@ class ParamStore:
         # leaving ten collectives (five heads + five 1,024-element tails at the end of the step) where one will do
         for rng in self.group_ranges.values():
             if b == rng['params'][1] and a >= rng['all'][0]:
+                if os.environ.get('S4F_CHECK_FLUSH') and self.grad is not None and rng['all'][1] > b:
+                    # debug: the tail (running statistics: no gradients) rides along in the all-reduce and must be zeros
+                    assert float(self.grad[b:rng['all'][1]].abs().max()) == 0.0, 'gradient arena: non-zero tail slots in a flushed span'
                 b = rng['all'][1]
                 break
         # merge with pending neighbours inside the group
