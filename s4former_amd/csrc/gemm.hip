@@ -331,6 +331,7 @@ int s4f_gemm2_try(const s4f_gemm_desc& d, hipStream_t st, int bn);   // gemm2.hi
 int s4f_gemm5_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm5.hip
 int s4f_gemm6_try(const s4f_gemm_desc& d, hipStream_t st);           // gemm6.hip
 int s4f_gemm6_grouped_try(const s4f_gemm_desc* ds, int count, hipStream_t st);
+int s4f_gemm5_grouped_try(const s4f_gemm_desc* ds, int count, hipStream_t st);   // gemm5.hip
 
 // 0 -> 128x128 kernel, 128 / 256 -> BN of the 256-row LDS-DMA kernel
 static int pick_tile(const s4f_gemm_desc& d) {
@@ -431,6 +432,28 @@ S4F_API int s4f_gemm_grouped(const s4f_gemm_desc* descs, int count, s4f_stream s
     if (rc != -100) {
       S4F_LAUNCH_CHECK();
       return rc;
+    }
+  }
+  // round 5: the 8-wave kernels (tile_hint 10) also take groups of implicit-GEMM convs - forward / input gradient (A gathered,
+  // B row-major, any epilogue of the one-tile kernel; split-K through fp32 atomics) and weight gradient (k = pixel) - the
+  // same-shape 32 x 32-stage convs of the four auxiliary heads as one grid each
+  if (same && count > 1 && d0.dtype == S4F_BF16 && d0.tile_hint == 10) {
+    bool ok5 = (d0.a_mode == S4F_OP_ROW_CONV || d0.a_mode == S4F_OP_ROW) && d0.b_mode == S4F_OP_ROW;
+    bool ok6 = d0.a_mode == S4F_OP_K && d0.b_mode == S4F_OP_K_CONV;
+    for (int i = 0; i < count && (ok5 || ok6); ++i) {
+      const s4f_gemm_desc& d = descs[i];
+      const bool basic = d.lda % 8 == 0 && d.ldb % 8 == 0 && ((uintptr_t)d.A % 16) == 0 && ((uintptr_t)d.B % 16) == 0 && !d.colsum &&
+                         (d.splitk <= 1 || (d.atomic && d.out_f32 && !d.out_t && d.act == S4F_ACT_NONE));
+      ok5 = ok5 && basic && d.K % 64 == 0 && (d.out_f32 || d.out_t) && (d.a_mode != S4F_OP_ROW_CONV || (d.cC % 64 == 0 && d.K == 9 * d.cC));
+      ok6 = ok6 && basic && d.atomic && d.out_f32 && !d.out_t && d.act == S4F_ACT_NONE && !d.bias && !d.resid && !d.pos && d.N % 256 == 0 &&
+            d.cC % 256 == 0 && d.N == 9 * d.cC;
+    }
+    if (ok5 || ok6) {
+      const int rc = ok5 ? s4f_gemm5_grouped_try(descs, count, (hipStream_t)stream) : s4f_gemm6_grouped_try(descs, count, (hipStream_t)stream);
+      if (rc != -100) {
+        S4F_LAUNCH_CHECK();
+        return rc;
+      }
     }
   }
   for (int i = 0; i < count; ++i) {

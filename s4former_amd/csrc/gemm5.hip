@@ -1083,7 +1083,82 @@ int launch5(const s4f_gemm_desc& d, hipStream_t st) {
   return 0;
 }
 
+// Up to four independent problems of the same operand modes in ONE grid (round 5): the same-shape small convs of the four
+// auxiliary heads (setr_up_head.py:51-77: conv 3 x 3 at the 32 x 32 stage, forward and input gradient: 32 - 96 tiles each,
+// launched one head after the other they ran at 190 - 330 TFLOP/s).  Work index = (problem, k-range, tile), cut into eight
+// contiguous ranges, one per XCD, as in gemm6.hip.
+struct GroupArgs5 {
+  GemmArgs p[kMaxGroup];
+  int work_end[kMaxGroup];                             // running sum of tiles x k-ranges over the problems
+};
+
+template <int AMODE>
+__global__ __launch_bounds__(512) void gemm5_grouped_kernel(const GroupArgs5 g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int total = g.work_end[kMaxGroup - 1];
+  int W = blockIdx.x;
+  {
+    const int xcd = W & 7, q8 = total >> 3, r8 = total & 7;
+    const int basei = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    W = basei + (W >> 3);
+  }
+  int which = 0;
+#pragma unroll
+  for (int i = 0; i < kMaxGroup - 1; ++i) which += W >= g.work_end[i] ? 1 : 0;
+  GemmArgs args = g.p[0];
+  int start = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (which == i) { args = g.p[i]; start = g.work_end[i - 1]; }
+  const int nt = args.tiles_m * args.tiles_n;
+  const int local = W - start;
+  const int z = local / nt, L = local - z * nt;
+  constexpr int GM = 8;
+  const int per_group = GM * args.tiles_n;
+  const int grp = L / per_group, r = L - grp * per_group;
+  const int rows_here = min(GM, args.tiles_m - grp * GM);
+  g5_body<AMODE, false, 0>(args, grp * GM + r % rows_here, r / rows_here, z, smem);
+}
+
+template <int AMODE>
+int launch5_grouped(const s4f_gemm_desc* ds, int count, hipStream_t st) {
+  GroupArgs5 g;
+  int total = 0;
+  for (int i = 0; i < kMaxGroup; ++i) {
+    const s4f_gemm_desc& d = ds[i < count ? i : count - 1];
+    GemmArgs& a = g.p[i];
+    a.d = d;
+    a.nk = ceil_div(d.K, BK);
+    int sk = d.splitk < 1 ? 1 : d.splitk;
+    if (sk > a.nk) sk = a.nk;
+    a.nk_per_split = ceil_div(a.nk, sk);
+    a.sk = ceil_div(a.nk, a.nk_per_split);
+    a.tiles_m = ceil_div(d.M, BM);
+    a.tiles_n = ceil_div(d.N, 256);
+    a.tail_rows = 0;
+    a.zgroup = 0;
+    const long a_bytes = (AMODE == S4F_OP_ROW) ? ((long)(d.M - 1) * d.lda + d.K) * 2 : (long)d.cB * d.cH * d.cW * d.lda * 2;
+    const long b_bytes = ((long)(d.N - 1) * d.ldb + d.K) * 2;
+    if (d.K % BK != 0 || a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return -100;
+    if (i < count) total += a.tiles_m * a.tiles_n * a.sk;
+    g.work_end[i] = total;
+  }
+  const size_t shm = 2 * (size_t)G5_BUF + 2 * (size_t)G5_TAILB;
+  static std::atomic<uint64_t> attr_set{0};       // one bit per device
+  auto kern = gemm5_grouped_kernel<AMODE>;
+  s4f_set_max_lds(attr_set, (const void*)kern, (int)shm);
+  hipLaunchKernelGGL(kern, dim3(total), dim3(512), shm, st, g);
+  return 0;
+}
+
 }  // namespace g5
+
+int s4f_gemm5_grouped_try(const s4f_gemm_desc* ds, int count, hipStream_t st) {
+  if (ds[0].dtype != S4F_BF16 || ds[0].b_mode != S4F_OP_ROW) return -100;
+  if (ds[0].a_mode == S4F_OP_ROW) return g5::launch5_grouped<S4F_OP_ROW>(ds, count, st);
+  if (ds[0].a_mode == S4F_OP_ROW_CONV) return g5::launch5_grouped<S4F_OP_ROW_CONV>(ds, count, st);
+  return -100;
+}
 
 int s4f_gemm5_try(const s4f_gemm_desc& d, hipStream_t st) {
   if (d.dtype != S4F_BF16 || d.b_mode != S4F_OP_ROW) return -100;

@@ -344,6 +344,7 @@ struct GroupArgs6 {
   int work_end[kMaxGroup];                             // running sum of tiles x k-ranges over the problems
 };
 
+template <int BMODE>
 __global__ __launch_bounds__(512) void gemm6_grouped_kernel(const GroupArgs6 g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int W = xcd_range(blockIdx.x, g.work_end[kMaxGroup - 1]);
@@ -360,7 +361,7 @@ __global__ __launch_bounds__(512) void gemm6_grouped_kernel(const GroupArgs6 g) 
   const int z = local / nt;
   int tm, tn;
   tile_of(args, local - z * nt, tm, tn);
-  g6_body<S4F_OP_K>(args, tm, tn, z, smem);
+  g6_body<BMODE>(args, tm, tn, z, smem);
 }
 
 static bool fill_args(GemmArgs& a, const s4f_gemm_desc& d) {
@@ -392,6 +393,7 @@ int launch6(const s4f_gemm_desc& d, hipStream_t st) {
   return 0;
 }
 
+template <int BMODE>
 int launch6_grouped(const s4f_gemm_desc* ds, int count, hipStream_t st) {
   GroupArgs6 g;
   int total = 0;
@@ -403,8 +405,8 @@ int launch6_grouped(const s4f_gemm_desc* ds, int count, hipStream_t st) {
   }
   const size_t shm = 2 * (size_t)G6_BUF + 4096;
   static std::atomic<uint64_t> attr_set{0};       // one bit per device
-  s4f_set_max_lds(attr_set, (const void*)gemm6_grouped_kernel, (int)shm);
-  hipLaunchKernelGGL(gemm6_grouped_kernel, dim3(total), dim3(512), shm, st, g);
+  s4f_set_max_lds(attr_set, (const void*)gemm6_grouped_kernel<BMODE>, (int)shm);
+  hipLaunchKernelGGL(gemm6_grouped_kernel<BMODE>, dim3(total), dim3(512), shm, st, g);
   return 0;
 }
 
@@ -418,5 +420,11 @@ int s4f_gemm6_try(const s4f_gemm_desc& d, hipStream_t st) {
 }
 
 int s4f_gemm6_grouped_try(const s4f_gemm_desc* ds, int count, hipStream_t st) {
-  return g6::launch6_grouped(ds, count, st);
+  // (round 5: also the conv weight gradients - k = pixel, the same-shape small convs of the four auxiliary heads in one grid)
+  if (ds[0].b_mode == S4F_OP_K_CONV) {
+    for (int i = 0; i < count; ++i)
+      if (ds[i].cC % 256 != 0) return -100;
+    return g6::launch6_grouped<S4F_OP_K_CONV>(ds, count, st);
+  }
+  return g6::launch6_grouped<S4F_OP_K>(ds, count, st);
 }

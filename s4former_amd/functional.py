@@ -382,7 +382,6 @@ def _attn_bwd_ws(Bn, N, H, device):
 
 _LAYER_PLANS = {}
 
-
 def _layer_plan(store, prm, M, E, F_, H, code, R):
     """static part of a layer's launch descriptor: parameter / shadow / gradient pointers and the tuned tile variants of its
     GEMMs; None when a signature is not in the tuning table yet (the per-kernel path then tunes it)"""
@@ -604,6 +603,12 @@ class LayerFn(Function):
         return (g0,) + (None,) * (6 + 12)
 
 
+# Round 5: heads advancing in lockstep (MultiHeadLossFn: the four auxiliary heads) issue their same-shape small convs - the
+# 32 x 32 stage: forward, input gradient, weight gradient - as ONE grouped grid each (s4f_gemm_grouped) instead of one launch per
+# head.  `=0`: one launch per head as before.
+GROUP_SMALL_CONVS = os.environ.get('S4F_GROUP_SMALL_CONVS', '1') != '0'
+
+
 # ============================================================================================== token un-shuffle
 class TokenGatherFn(Function):
     """out.rows = tokens.rows[fwd]  over the flattened [B * (T + 1), E] token tensor: the decode head's un-shuffle of a
@@ -640,6 +645,25 @@ class _Exchange:
     def __init__(self, nheads, world):
         self.n, self.world = nheads, world
         self.buf, self.i = None, 0
+        self.gemms = []                               # (args, kwargs, side tensors or None) asked for in this round
+
+    def gemm(self, *args, side=None, **kw):
+        """a GEMM that the heads of a lockstep group issue TOGETHER (round 5): registered here, launched - as ONE grouped grid when
+        several heads ask in the same round - when the generator yields 'gemm'.  side: tensors read by a launch that belongs on
+        the weight-gradient stream."""
+        self.gemms.append((args, kw, side))
+
+    def flush_gemms(self):
+        reqs, self.gemms = self.gemms, []
+        if not reqs:
+            return
+        side = reqs[0][2]
+        if side is not None:
+            tens = [t for _, _, sd in reqs for t in sd]
+            with on_side(tens[0].device, *tens):
+                K.gemm_group([(a, kw) for a, kw, _ in reqs])
+        else:
+            K.gemm_group([(a, kw) for a, kw, _ in reqs])
 
     def alloc(self, size, dev):
         if self.buf is None or self.i >= self.n:
@@ -666,17 +690,20 @@ def _drive(gens, ex):
     out = [None] * len(gens)
     live = list(range(len(gens)))
     while live:
-        nxt = []
+        nxt, kinds = [], set()
         for i in live:
             try:
-                next(gens[i])
+                kinds.add(next(gens[i]))
                 nxt.append(i)
             except StopIteration as e:
                 out[i] = e.value
         if nxt:
-            if len(nxt) != len(live):
-                raise S4FError('lockstep heads must have the same number of SyncBN layers')
-            ex.reduce()
+            if len(nxt) != len(live) or len(kinds) != 1:
+                raise S4FError('lockstep heads must have the same structure (SyncBN layers, grouped launches)')
+            if 'gemm' in kinds:
+                ex.flush_gemms()                      # the round's GEMM requests as one grouped launch
+            else:
+                ex.reduce()
         live = nxt
     return out
 
@@ -727,8 +754,15 @@ def _head_forward_gen(tokens, hp, store, training, save, ex):
         elif code == BF16 and _tiles256(Mp, Cc) < 96:
             # few output tiles (the 32x32 stage): split the 9*cin contraction over blocks, fp32 partial sums
             yf = torch.zeros(Mp, Cc, device=dev)
-            K.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_f32=yf,
-                   ldo_f32=Cc, atomic=True, splitk=max(2, min(16, 192 // _tiles256(Mp, Cc))), conv=(Bn, h, w, cin, 1))
+            if GROUP_SMALL_CONVS and ex.n > 1:
+                # lockstep heads: the same-shape convs of all of them as ONE grid (s4f_gemm_grouped, 8-wave kernel, the k-ranges
+                # sized for the group: n x tiles x splits ~ one block per CU)
+                ex.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_f32=yf, ldo_f32=Cc,
+                        atomic=True, splitk=max(1, min(16, 256 // (ex.n * _tiles256(Mp, Cc)))), conv=(Bn, h, w, cin, 1), tile_hint=10)
+                yield 'gemm'
+            else:
+                K.gemm(cur, store.shadow(cv['w']), Mp, Cc, 9 * cin, cin, 9 * cin, code, a_mode=K.OP_ROW_CONV, out_f32=yf,
+                       ldo_f32=Cc, atomic=True, splitk=max(2, min(16, 192 // _tiles256(Mp, Cc))), conv=(Bn, h, w, cin, 1))
             K.cast(yf, y, code)
         else:
             # training: the BatchNorm statistics (column sums and sums of squares of y as stored) come out of the conv GEMM's
@@ -863,10 +897,18 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
         del g
         st['y'] = None
         # conv weight gradient [Cc][3][3][cin] += dy^T (shifted inp)
-        with on_side(dev, dy, st['inp']):
-            K.gemm(dy, st['inp'], Cc, 9 * cin_k, Mk, Cc, cin_k, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV,
-                   out_f32=store.grad_phys(cv['w']), ldo_f32=9 * cin_k, atomic=True,
-                   splitk=_splitk(_tiles(Cc, 9 * cin_k), _nk(Mk, code), target=768), conv=(Bn, h, w, cin_k, 1))
+        small = GROUP_SMALL_CONVS and ex.n > 1 and code == BF16 and _tiles256(Mk, cin_k) < 128 and cin_k % 256 == 0
+        if small:
+            ex.gemm(dy, st['inp'], Cc, 9 * cin_k, Mk, Cc, cin_k, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV,
+                    out_f32=store.grad_phys(cv['w']), ldo_f32=9 * cin_k, atomic=True,
+                    splitk=max(1, min(_nk(Mk, code), 256 // (ex.n * _tiles256(Cc, 9 * cin_k)))), conv=(Bn, h, w, cin_k, 1), tile_hint=10,
+                    side=(dy, st['inp']))
+            yield 'gemm'
+        else:
+            with on_side(dev, dy, st['inp']):
+                K.gemm(dy, st['inp'], Cc, 9 * cin_k, Mk, Cc, cin_k, code, a_mode=K.OP_K, b_mode=K.OP_K_CONV,
+                       out_f32=store.grad_phys(cv['w']), ldo_f32=9 * cin_k, atomic=True,
+                       splitk=_splitk(_tiles(Cc, 9 * cin_k), _nk(Mk, code), target=768), conv=(Bn, h, w, cin_k, 1))
         st['inp'] = None
         dcur = torch.empty(Mk, cin_k, device=dev, dtype=T)
         # input gradient = the same implicit GEMM with mirrored taps (csign -1).  bf16: against the [ci][tap][co] shadow
@@ -877,8 +919,13 @@ def _head_backward_gen(dlo, dlo_t, sv, hp, store, ex):
             wB, bm, ldb = store.shadow(cv['w']), K.OP_K_TAPSPLIT, 9 * cin_k
         if code == BF16 and _tiles256(Mk, cin_k) < 128:
             df = torch.zeros(Mk, cin_k, device=dev)
-            K.gemm(dy, wB, Mk, cin_k, 9 * Cc, Cc, ldb, code, a_mode=K.OP_ROW_CONV, b_mode=bm, out_f32=df, ldo_f32=cin_k,
-                   atomic=True, splitk=max(2, min(8, 256 // _tiles256(Mk, cin_k))), conv=(Bn, h, w, Cc, -1))
+            if small:
+                ex.gemm(dy, wB, Mk, cin_k, 9 * Cc, Cc, ldb, code, a_mode=K.OP_ROW_CONV, b_mode=bm, out_f32=df, ldo_f32=cin_k,
+                        atomic=True, splitk=max(1, min(8, 256 // (ex.n * _tiles256(Mk, cin_k)))), conv=(Bn, h, w, Cc, -1), tile_hint=10)
+                yield 'gemm'
+            else:
+                K.gemm(dy, wB, Mk, cin_k, 9 * Cc, Cc, ldb, code, a_mode=K.OP_ROW_CONV, b_mode=bm, out_f32=df, ldo_f32=cin_k,
+                       atomic=True, splitk=max(2, min(8, 256 // _tiles256(Mk, cin_k))), conv=(Bn, h, w, Cc, -1))
             K.cast(df, dcur, code)
         else:
             K.gemm(dy, wB, Mk, cin_k, 9 * Cc, Cc, ldb, code, a_mode=K.OP_ROW_CONV, b_mode=bm, out_t=dcur, ldo_t=cin_k,

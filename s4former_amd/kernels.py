@@ -265,6 +265,33 @@ def _t256(M, N):
     return -(-M // 256) * -(-N // 256)
 
 
+def gemm_group(requests):
+    """requests: 1..n (args, kwargs) of gemm(...) whose tile_hint / splitk are FIXED by the caller (no tuning, no folding): one
+    s4f_gemm_grouped launch per four of them (round 5: the same-shape small convs of the auxiliary heads advancing in lockstep).
+    The C side runs a group it has no kernel for one problem after the other - same results either way."""
+    global _collect
+    if len(requests) == 1:
+        a, kw = requests[0]
+        gemm(*a, **kw)
+        return
+    for i in range(0, len(requests), 4):
+        chunk = requests[i:i + 4]
+        _collect = []
+        try:
+            for a, kw in chunk:
+                kw = dict(kw)
+                if kw.get('colsum') is not None or kw.get('colstats') is not None or not kw.get('tile_hint'):
+                    raise S4FError('gemm_group: grouped launches take a fixed tile_hint and no folded column sums')
+                gemm(*a, **kw)
+            descs = _collect
+        finally:
+            _collect = None
+        arr = (L.GemmDesc * len(descs))(*descs)
+        a0, kw0 = chunk[0]
+        call('s4f_gemm_grouped', arr, len(descs), stream(),
+             tag=(kw0.get('a_mode', OP_ROW), kw0.get('b_mode', OP_ROW), sum(a[2] for a, _ in chunk), a0[3], a0[4]))
+
+
 def wgrad_grouped(problems, dtype):
     """problems: up to 4 tuples (dy[rows, M], x[rows, N], M, N, rows, out fp32 [M, N]); out += dy^T x for each.  One
     launch for all of them in bf16 (s4f_gemm_grouped); the (tile variant, split-K) pair is tuned once per group."""
