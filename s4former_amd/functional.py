@@ -417,6 +417,8 @@ def _layer_plan(store, prm, M, E, F_, H, code, R):
         wg = (4, wg[1])
     if os.environ.get('S4F_WG_SPLITK'):      # experiment: k-ranges of the layer's grouped weight gradient (108 tiles x k-ranges blocks)
         wg = (wg[0], int(os.environ['S4F_WG_SPLITK']))
+    if os.environ.get('S4F_WG_HINT'):        # experiment (round 5): tile variant of the layer's grouped weight gradient (2 = 256 x 128, 8 waves)
+        wg = (int(os.environ['S4F_WG_HINT']), wg[1])
     d = L_.LayerDesc()
     d.E, d.F, d.H, d.dtype, d.xdtype = E, F_, H, code, (BF16 if rt else F32)
     for i in range(8):

@@ -6,7 +6,10 @@ import sys
 
 c = sqlite3.connect(sys.argv[1])
 rows = list(c.execute("select name,start,end,grid_x,grid_y,grid_z,workgroup_x,queue_id from kernels order by start"))
+# (step boundaries: the EMA launch at the head of a step - or, with the double-buffered teacher of round 5, the first of the step's two patch-embedding gathers)
 em = [r[1] for r in rows if 'ema_kernel' in r[0]]
+if len(em) < 4:
+    em = sorted(r[1] for r in rows if 'im2col16' in r[0])[0::2]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 t0, t1 = em[-k - 1], em[-k]
 R = [r for r in rows if t0 <= r[1] < t1]

@@ -19,11 +19,20 @@ def kernel_src_sha():
     return h.hexdigest()[:16]
 
 
+def _step_marks(rows):
+    """row indices where a step starts: the EMA launch or, with the double-buffered teacher (round 5), the first of the step's two
+    patch-embedding gathers"""
+    ema = [i for i, r in enumerate(rows) if 'ema_kernel' in r['Kernel_Name']]
+    if len(ema) < 3:
+        ema = [i for i, r in enumerate(rows) if 'im2col16' in r['Kernel_Name']][0::2]
+    return ema
+
+
 def per_kernel(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
     # dispatches are in launch order; the EMA kernel marks the start of a step: keep the last complete step
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
-    ema = [i for i, r in enumerate(rows) if 'ema_kernel' in r['Kernel_Name']]
+    ema = _step_marks(rows)
     a, b = ema[-2], ema[-1]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows[a:b]:
@@ -38,7 +47,7 @@ def by_kernel(path, counter):
     """{(kernel, blocks): [launches, KB]} over the last complete step, every kernel (not only the GEMM family)"""
     rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
-    ema = [i for i, r in enumerate(rows) if 'ema_kernel' in r['Kernel_Name']]
+    ema = _step_marks(rows)
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in rows[ema[-2]:ema[-1]]:
         name = r['Kernel_Name'].replace('void ', '').replace('(anonymous namespace)::', '')
