@@ -339,7 +339,7 @@ static int pick_tile(const s4f_gemm_desc& d) {
   if (d.tile_hint == 1) return 0;
   if (d.tile_hint == 2) return 128;
   if (d.tile_hint == 3 || d.tile_hint == 4) return 256;
-  if (d.tile_hint >= 10 && d.tile_hint <= 14) return 2048;                       // 8-wave ping-pong kernel (gemm5.hip)
+  if (d.tile_hint >= 10 && d.tile_hint <= 15) return 2048;                       // 8-wave ping-pong kernel (gemm5.hip)
   if (d.tile_hint == 8 || d.tile_hint == 9) return 192;     // 256 x 192 tile, 16 / 8 waves (token GEMMs with N = 768, 2304)
   const long sk = d.splitk < 1 ? 1 : d.splitk;
   const long t256 = (long)ceil_div(d.M, 256) * ceil_div(d.N, 256) * sk;

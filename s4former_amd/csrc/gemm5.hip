@@ -48,7 +48,10 @@ __device__ __forceinline__ void bufl16(__amdgpu_buffer_rsrc_t rsrc, int voff, in
 // (dense) or over a filter tap (conv gather); the k position is the scalar offset.  Rows outside the problem, conv
 // padding and K-tiles past the block's k range get an out-of-range offset: the hardware returns zeros (no zero page,
 // no memory traffic).
-template <int MODE, bool IS_A>
+// BNT = 192 (round 5, tile_hint 15): a 256 x 192 tile - N = 768 is then 4 tile columns, 256 tiles for 256 CUs at 16,384 rows instead
+// of 192 tiles of 256 x 256.  Each wave's strip is 48 columns: BL = its first 32 (two DMAs per wave: 16 blocks of 8 rows),
+// BH = its last 16 (ONE DMA per wave: 8 blocks).
+template <int MODE, bool IS_A, int BNT = 256>
 struct PFeeder {
   __amdgpu_buffer_rsrc_t rsrc;
   long ld;
@@ -67,6 +70,10 @@ struct PFeeder {
   __device__ __forceinline__ int block_of(int u) const {
     const int part = u >> 1, i = u & 1;
     if constexpr (IS_A) return wave + 16 * i + 8 * part;
+    if constexpr (BNT == 192) {
+      if (part == 0) { const int e = wave + 8 * i; return 6 * (e >> 2) + (e & 3); }
+      return 6 * (wave >> 1) + 4 + (wave & 1);         // (slot 3 does not exist)
+    }
     const int e = wave + 8 * i;
     return 8 * (e >> 2) + (e & 3) + 4 * part;
   }
@@ -157,16 +164,20 @@ struct PFeeder {
     const int so = kt * (BK * 2) - (MODE == S4F_OP_ROW_CONV ? soff[PART] : 0) + ((!IS_A && MODE == S4F_OP_ROW) ? bdelta[PART] : 0);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (!IS_A && BNT == 192 && PART == 1 && i == 1) break;
       const int u = 2 * PART + i;
       bufl16(rsrc, live ? voff[u] : G5_OOB, so, img + block_of(u) * 1024);
     }
   }
 };
 
-template <int AMODE, bool TAIL, int DBG = 0>
+template <int AMODE, bool TAIL, int DBG = 0, int BNT = 256>
 __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, const int tn, const int bz, char* smem) {
   const s4f_gemm_desc& d = args.d;
-  const int m0 = tm * BM, n0 = tn * 256;
+  constexpr int WCOL = BNT / 4;                        // columns of a wave's strip: 64 | 48
+  constexpr int NJ = WCOL / 16;                        // its 16-column sub-tiles: 4 | 3 (BL = sub-tiles 0, 1; BH = 2 (, 3))
+  constexpr int NPW = (BNT == 192 ? 7 : 8) + (TAIL ? 1 : 0);   // DMA instructions of the four younger parts
+  const int m0 = tm * BM, n0 = tn * BNT;
   const int kt_beg = bz * args.nk_per_split;
   int kt_end = kt_beg + args.nk_per_split;
   if (kt_end > args.nk) kt_end = args.nk;
@@ -176,7 +187,7 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
   const int l = threadIdx.x & 63, g = l >> 4, li = l & 15;
 
   PFeeder<AMODE, true> fa;
-  PFeeder<S4F_OP_ROW, false> fb;
+  PFeeder<S4F_OP_ROW, false, BNT> fb;
   int rot = -1;
   if constexpr (AMODE == S4F_OP_ROW_CONV) {
     // the tile is R = 256 / cW whole image rows starting at row y (R = 1 at the 256 x 256 stage): phase = (y + dy) % 3
@@ -220,17 +231,13 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
     tail_issue(kt_beg + 1, 1);
     fb.template issue<P_BL>(kt_beg + 1, b1 + G5_A);
   }
-  if constexpr (TAIL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();         // stagger: the lower half runs one barrier behind
 
   Frag<bf16_t> a[4][2], bl[2][2], bh[2][2], ta[2];
 
-  auto wait_parts = [&]() {
-    if constexpr (TAIL) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  };
+  auto wait_parts = [&]() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory"); };
   auto read_a = [&](const char* As, int half) {       // 64 rows x 64 k of this wave's 128-row half
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -241,7 +248,10 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) frag_row<false>(b[j][s], Bs, wc * 64 + half * 32 + j * 16, s);
+      for (int j = 0; j < 2; ++j) {
+        if (BNT == 192 && half == 1 && j == 1) break;  // (the high part of a 48-column strip is one sub-tile)
+        frag_row<false>(b[j][s], Bs, wc * WCOL + half * 32 + j * 16, s);
+      }
   };
   auto mma_quad = [&](auto ahc, auto bhc, const Frag<bf16_t> (&b)[2][2]) {
     constexpr int AH = decltype(ahc)::value, BH = decltype(bhc)::value;
@@ -250,7 +260,8 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[AH * 4 + i][BH * 2 + j] = mma16(a[i][s], b[j][s], acc[AH * 4 + i][BH * 2 + j]);
+        for (int j = 0; j < ((BNT == 192 && BH == 1) ? 1 : 2); ++j)
+          acc[AH * 4 + i][BH * 2 + j] = mma16(a[i][s], b[j][s], acc[AH * 4 + i][BH * 2 + j]);
   };
   auto seg_begin = [&]() {
     __builtin_amdgcn_sched_barrier(0);
@@ -305,7 +316,7 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) tacc[j] = mma16(ta[s], bh[j][s], tacc[j]);
+          for (int j = 0; j < (BNT == 192 ? 1 : 2); ++j) tacc[j] = mma16(ta[s], bh[j][s], tacc[j]);
       }
     }
     seg_end();
@@ -346,7 +357,7 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
   }
   // ------------------------------------------------------------------ epilogue (same contract as gemm2.hip)
   const bool first_split = (bz == 0);
-  const bool wide = (d.N % 8 == 0) && (n0 + 256 <= d.N) && (!d.atomic || (d.act == S4F_ACT_NONE && !d.out_t && !d.pos)) &&
+  const bool wide = (d.N % 8 == 0) && (n0 + BNT <= d.N) && (!d.atomic || (d.act == S4F_ACT_NONE && !d.out_t && !d.pos)) &&
                     (!d.out_t || d.ldo_t % 8 == 0) && (!d.out_pre || d.ldo_pre % 8 == 0) && (!d.aux || d.ld_aux % 8 == 0) &&
                     (!d.out_f32 || d.ldo_f32 % 4 == 0) && (!d.resid || d.ldr % (d.resid_t ? 8 : 4) == 0);
   // bf16 outputs (bias only: qkv, the input gradients, conv fwd / dgrad; GELU with its derivative: fc1; times a gelu'
@@ -358,15 +369,15 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
   const bool plain_t = wide && d.out_t && !d.out_f32 && (!d.resid || (d.resid_t && d.act == S4F_ACT_NONE)) && !d.pos && !d.atomic &&
                        (d.act == S4F_ACT_NONE ? !d.out_pre : true);
   if (plain_t) {
-    constexpr int LDB = 256 + 8;                     // staged row = 528 B
+    constexpr int LDB = BNT + 8;                     // staged row = 528 | 400 B
     bf16_t* tb = reinterpret_cast<bf16_t*>(smem);
     bf16_t* out_t = reinterpret_cast<bf16_t*>(d.out_t);
     bf16_t* out_pre = reinterpret_cast<bf16_t*>(d.out_pre);
     const bf16_t* aux = reinterpret_cast<const bf16_t*>(d.aux);
     const bf16_t* res_t = reinterpret_cast<const bf16_t*>(d.resid);
-    static_for<4>([&](auto jc) {
+    static_for<NJ>([&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      const int col = wc * 64 + j * 16 + li;
+      const int col = wc * WCOL + j * 16 + li;
       const float bias = d.bias ? d.bias[n0 + col] : 0.f;
       static_for<8>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -387,9 +398,10 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
     float cs[8], cq[8];                              // column sums (and sums of squares) of what this thread stores (its 8 columns never change)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
+    constexpr int CH = BNT / 8;                      // 16-byte chunks per staged row
 #pragma unroll 4
-    for (int idx = threadIdx.x; idx < NROWS * 32; idx += 512) {
-      const int row = idx >> 5, cc = idx & 31;
+    for (int idx = threadIdx.x; idx < NROWS * CH; idx += 512) {
+      const int row = idx / CH, cc = idx - row * CH;
       const int m = m0 + row;
       if (m >= d.M) continue;
       bf16x8 v = *reinterpret_cast<const bf16x8*>(tb + row * LDB + cc * 8);
@@ -468,38 +480,40 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
   if (wide) {
     // fp32 staging (residual / fp32 / atomic outputs): two passes of 128 staged rows; in pass p EVERY wave stages rows
     // 64 p .. 64 p + 63 of its 128-row half (staged rows 0-63: upper half of the tile, 64-127: lower half)
-    constexpr int LDT = 256 + 4;
+    constexpr int LDT = BNT + 4;
     float* tile = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       __syncthreads();
       static_for<4>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        static_for<4>([&](auto jc) {
+        static_for<NJ>([&](auto jc) {
           constexpr int j = decltype(jc)::value;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            tile[(wr * 64 + i * 16 + 4 * g + r) * LDT + wc * 64 + j * 16 + li] = pass == 0 ? acc[i][j][r] : acc[4 + i][j][r];
+            tile[(wr * 64 + i * 16 + 4 * g + r) * LDT + wc * WCOL + j * 16 + li] = pass == 0 ? acc[i][j][r] : acc[4 + i][j][r];
         });
       });
       __syncthreads();
-      epilogue_rows<256, 8, 64>(d, tile, m0 + pass * 64, n0, first_split);
-      epilogue_rows<256, 8, 64>(d, tile + 64 * LDT, m0 + 128 + pass * 64, n0, first_split);
+      epilogue_rows<BNT, 8, 64>(d, tile, m0 + pass * 64, n0, first_split);
+      epilogue_rows<BNT, 8, 64>(d, tile + 64 * LDT, m0 + 128 + pass * 64, n0, first_split);
     }
     if constexpr (TAIL) {
       __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j) {
+        if (BNT == 192 && wr == 1 && j == 1) break;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) tile[(4 * g + r) * LDT + wc * 64 + wr * 32 + j * 16 + li] = tacc[j][r];
+        for (int r = 0; r < 4; ++r) tile[(4 * g + r) * LDT + wc * WCOL + wr * 32 + j * 16 + li] = tacc[j][r];
+      }
       __syncthreads();
-      epilogue_rows<256, 8, 64>(d, tile, m0 + 256, n0, first_split);
+      epilogue_rows<BNT, 8, 64>(d, tile, m0 + 256, n0, first_split);
     }
     return;
   }
-  static_for<4>([&](auto jc) {
+  static_for<NJ>([&](auto jc) {
     constexpr int j = decltype(jc)::value;
-    const int n = n0 + wc * 64 + j * 16 + li;
+    const int n = n0 + wc * WCOL + j * 16 + li;
     if (n < d.N) {
       const float bias = (d.bias && first_split) ? d.bias[n] : 0.f;
       static_for<8>([&](auto ic) {
@@ -1030,7 +1044,7 @@ int launch5p(const s4f_gemm_desc& d, hipStream_t st, int nwg) {
   return 0;
 }
 
-template <int AMODE, int DBG>
+template <int AMODE, int DBG, int BNT = 256>
 __global__ __launch_bounds__(512) void gemm5_kernel(const GemmArgs args) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // XCD-aware bijective remap + grouped tile order (as gemm2.hip)
@@ -1047,11 +1061,11 @@ __global__ __launch_bounds__(512) void gemm5_kernel(const GemmArgs args) {
   const int rows_here = min(GM, args.tiles_m - grp * GM);
   const int tm = grp * GM + r % rows_here;
   const int tn = r / rows_here;
-  if (AMODE == S4F_OP_ROW && args.tail_rows > 0 && tm == args.tiles_m - 1) g5_body<AMODE, true, DBG>(args, tm, tn, blockIdx.z, smem);
-  else g5_body<AMODE, false, DBG>(args, tm, tn, blockIdx.z, smem);
+  if (AMODE == S4F_OP_ROW && args.tail_rows > 0 && tm == args.tiles_m - 1) g5_body<AMODE, true, DBG, BNT>(args, tm, tn, blockIdx.z, smem);
+  else g5_body<AMODE, false, DBG, BNT>(args, tm, tn, blockIdx.z, smem);
 }
 
-template <int AMODE, int DBG = 0>
+template <int AMODE, int DBG = 0, int BNT = 256>
 int launch5(const s4f_gemm_desc& d, hipStream_t st) {
   GemmArgs a;
   a.d = d;
@@ -1060,7 +1074,7 @@ int launch5(const s4f_gemm_desc& d, hipStream_t st) {
   if (sk > a.nk) sk = a.nk;
   a.nk_per_split = ceil_div(a.nk, sk);
   sk = ceil_div(a.nk, a.nk_per_split);
-  a.tiles_n = ceil_div(d.N, 256);
+  a.tiles_n = ceil_div(d.N, BNT);
   a.sk = sk;
   a.zgroup = 0;
   const int rem = d.M % BM;
@@ -1077,7 +1091,7 @@ int launch5(const s4f_gemm_desc& d, hipStream_t st) {
   if (d.K % BK != 0 || a_bytes >= (1L << 31) || b_bytes >= (1L << 31)) return -100;
   const size_t shm = 2 * (size_t)G5_BUF + 2 * (size_t)G5_TAILB;     // 144 KiB (epilogue staging tile: 130 KiB)
   static std::atomic<uint64_t> attr_set{0};       // one bit per device
-  auto kern = gemm5_kernel<AMODE, DBG>;
+  auto kern = gemm5_kernel<AMODE, DBG, BNT>;
   s4f_set_max_lds(attr_set, (const void*)kern, (int)shm);
   hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n, 1, sk), dim3(512), shm, st, a);
   return 0;
@@ -1177,6 +1191,12 @@ int s4f_gemm5_try(const s4f_gemm_desc& d, hipStream_t st) {
       const int rc = g5::launch5p<>(d, st, cus);
       if (rc != -100) return rc;
     }
+  }
+  // tile_hint 15 (round 5): the 256 x 192 tile of the same schedule - N = 768 as 4 tile columns (256 tiles at 16,384 rows: every
+  // CU gets one, where 256 x 256 tiles leave 64 CUs idle); dense row-major operands, no folded column sums
+  if (d.tile_hint == 15) {
+    if (d.a_mode != S4F_OP_ROW || d.N % 192 != 0 || d.colsum) return -100;
+    return g5::launch5<S4F_OP_ROW, 0, 192>(d, st);
   }
   if (d.a_mode == S4F_OP_ROW) return g5::launch5<S4F_OP_ROW>(d, st);
   if (d.a_mode == S4F_OP_ROW_CONV) return g5::launch5<S4F_OP_ROW_CONV>(d, st);

@@ -690,7 +690,7 @@ def test_ema_sgd(K, code):
 
 
 # ------------------------------------------------------------------------------------------------ 256-row LDS-DMA kernel
-@pytest.mark.parametrize('hint', [2, 3, 4, 8, 9, 10])
+@pytest.mark.parametrize('hint', [2, 3, 4, 8, 9, 10, 15])
 def test_gemm2_dense_modes(K, hint):
     code = 1
     M, N, K_ = 1000, 768, 832
@@ -727,7 +727,7 @@ def test_gemm2_dense_modes(K, hint):
     assert float(o21[:, 21:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('hint', [3, 4, 8, 9, 10])
+@pytest.mark.parametrize('hint', [3, 4, 8, 9, 10, 15])
 @pytest.mark.parametrize('M', [2 * 1025, 2 * 1025 + 6, 512 + 16, 256 + 1, 256 + 17, 255])
 def test_gemm2_folded_tail(K, hint, M):
     """token GEMMs have M = B * 1025: a row remainder <= 16 is folded into the last tile row (hints 3/4/8/9), 17 is not;
@@ -891,7 +891,7 @@ def test_gemm_persistent(K, M, N, K_):
     assert torch.equal(o2, outs[13])
 
 
-@pytest.mark.parametrize('hint', [4, 10])
+@pytest.mark.parametrize('hint', [4, 10, 15])
 @pytest.mark.parametrize('M,N,K_', [(1024 + 16, 768, 4096), (777, 512, 2304 + 64)])
 def test_gemm_long_k_pipeline(K, hint, M, N, K_):
     """many K-tiles through the LDS rings (counted-vmcnt pipeline of hint 10: 64 / 37 K-tiles, odd count included), several

@@ -1,0 +1,6 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+for i in 1 2; do
+for cfg in "A=1" "S4F_TUNE_CACHE=$GRAFT_REPO_ROOT/tools/exp/tuned_h15_a.json" "S4F_TUNE_CACHE=$GRAFT_REPO_ROOT/tools/exp/tuned_h15_b.json" "S4F_TUNE_CACHE=$GRAFT_REPO_ROOT/tools/exp/tuned_h15_c.json"; do
+  echo -n "[${cfg##*/}] "; env $cfg timeout -k 10 250 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-profile --no-parity-mode 2>/dev/null | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['ms_per_step_windows'])"
+done; done
