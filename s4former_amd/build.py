@@ -28,9 +28,11 @@ if os.environ.get('S4F_FB_ABL'):      # ablation builds of the one-sweep attenti
     FILE_FLAGS['attn_bwd.hip'] = FILE_FLAGS['attn_bwd.hip'] + ['-DFB_ABL=' + os.environ['S4F_FB_ABL']]
 if os.environ.get('S4F_G5P_AUTO'):    # A/B build: S4F_G5P_AUTO=0 keeps tile_hint 10 on the one-tile kernel
     FILE_FLAGS['gemm5.hip'] = FILE_FLAGS.get('gemm5.hip', FLAGS) + ['-DG5P_AUTO=' + os.environ['S4F_G5P_AUTO']]
+if os.environ.get('S4F_G5_ST_AUX'):  # A/B build: cache policy bits of the ping-pong GEMM's bf16 output stores (16 = sc1)
+    FILE_FLAGS['gemm5.hip'] = FILE_FLAGS.get('gemm5.hip', FLAGS) + ['-DG5_ST_AUX=' + os.environ['S4F_G5_ST_AUX']]
 if os.environ.get('S4F_G5_PROBES'):
     FILE_FLAGS['gemm5.hip'] = FILE_FLAGS.get('gemm5.hip', FLAGS) + ['-DG5_PROBES']
-_DIAG = [v for v in ('S4F_FB_STAMPS', 'S4F_FB_ABL', 'S4F_G5_PROBES', 'S4F_G5P_AUTO') if os.environ.get(v)]
+_DIAG = [v for v in ('S4F_FB_STAMPS', 'S4F_FB_ABL', 'S4F_G5_PROBES', 'S4F_G5P_AUTO', 'S4F_G5_ST_AUX') if os.environ.get(v)]
 if _DIAG and not os.environ.get('S4F_LIB_OUT'):
     # stamp / ablation builds compute wrong results by construction: they never overwrite the shipped library
     raise RuntimeError(f'{", ".join(_DIAG)} select a diagnostic build: set S4F_LIB_OUT=<path of the experiment library> as well')

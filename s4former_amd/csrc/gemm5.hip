@@ -399,6 +399,9 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
 #pragma unroll
     for (int e = 0; e < 8; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
     constexpr int CH = BNT / 8;                      // 16-byte chunks per staged row
+#if G5_ST_AUX
+    __amdgpu_buffer_rsrc_t st_rsrc = __builtin_amdgcn_make_buffer_rsrc(d.out_t, 0, (int)(unsigned)((((long)d.M - 1) * d.ldo_t + d.N) * 2), 0x00020000);
+#endif
 #pragma unroll 4
     for (int idx = threadIdx.x; idx < NROWS * CH; idx += 512) {
       const int row = idx / CH, cc = idx - row * CH;
@@ -439,7 +442,14 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)rr[e]);
       }
+#if G5_ST_AUX
+      {
+        typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), st_rsrc, (int)(unsigned)(((long)m * d.ldo_t + n) * 2), 0, G5_ST_AUX);
+      }
+#else
       *reinterpret_cast<bf16x8*>(out_t + (long)m * d.ldo_t + n) = v;
+#endif
       if (d.colsum) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) cs[e] += (float)v[e];
@@ -542,6 +552,9 @@ __device__ __forceinline__ void g5_body(const GemmArgs& args, const int tm, cons
 // in-order counter, so the counted waits of the first K-tile behind an epilogue allow for the NST stores that sit between the
 // prefetched parts and the parts issued after them (vmcnt(8 + NST)); from the second K-tile on the plain count applies.
 // Only the T-output epilogues of the dense token GEMMs (bias; GELU + gelu'; x gelu' with folded column sums) take this path.
+#ifndef G5_ST_AUX
+#define G5_ST_AUX 0       // cache policy of the bf16 output stores (16 = sc1: the line is dropped from the XCD's L2 behind the store)
+#endif
 #ifndef G5P_AUTO
 #define G5P_AUTO 1        // 0: tile_hint 10 never takes the persistent form (same-box A/B builds)
 #endif
@@ -906,7 +919,7 @@ __global__ __launch_bounds__(512) void gemm5p_kernel(const GemmArgs args, const 
 #pragma unroll
           for (int e = 0; e < 8; ++e) pv[e] = (bf16_t)gdv[e];
           const unsigned off = m < d.M ? (unsigned)(((long)m * d.ldo_pre + col) * 2) : 0xfffffff0u;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pv), prsrc, (int)off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, pv), prsrc, (int)off, 0, G5_ST_AUX);
         }
       } else if constexpr (ACT == S4F_ACT_GELU_BWD) {
         const long mm = m < d.M ? m : 0;             // rows beyond M: read row 0, stored nowhere
@@ -922,7 +935,7 @@ __global__ __launch_bounds__(512) void gemm5p_kernel(const GemmArgs args, const 
       }
       {
         const unsigned off = m < d.M ? (unsigned)(((long)m * d.ldo_t + col) * 2) : 0xfffffff0u;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), orsrc, (int)off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o), orsrc, (int)off, 0, G5_ST_AUX);
       }
       if (d.colsum && m < d.M) {
 #pragma unroll
