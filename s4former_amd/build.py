@@ -32,7 +32,11 @@ if os.environ.get('S4F_G5_ST_AUX'):  # A/B build: cache policy bits of the ping-
     FILE_FLAGS['gemm5.hip'] = FILE_FLAGS.get('gemm5.hip', FLAGS) + ['-DG5_ST_AUX=' + os.environ['S4F_G5_ST_AUX']]
 if os.environ.get('S4F_G5_PROBES'):
     FILE_FLAGS['gemm5.hip'] = FILE_FLAGS.get('gemm5.hip', FLAGS) + ['-DG5_PROBES']
-_DIAG = [v for v in ('S4F_FB_STAMPS', 'S4F_FB_ABL', 'S4F_G5_PROBES', 'S4F_G5P_AUTO', 'S4F_G5_ST_AUX') if os.environ.get(v)]
+if os.environ.get('S4F_EXTRA_DEFS'):  # experiment builds: extra -D switches for every source (space separated, e.g. "FB_PRE_ORDER=1")
+    for _f in ('gemm.hip', 'gemm2.hip', 'gemm5.hip', 'gemm6.hip', 'attention.hip', 'attn_bwd.hip', 'elementwise.hip', 'head.hip',
+               'eval.hip', 'pipeline.hip', 'layer.hip'):
+        FILE_FLAGS[_f] = FILE_FLAGS.get(_f, FLAGS) + ['-D' + d for d in os.environ['S4F_EXTRA_DEFS'].split()]
+_DIAG = [v for v in ('S4F_FB_STAMPS', 'S4F_FB_ABL', 'S4F_G5_PROBES', 'S4F_G5P_AUTO', 'S4F_G5_ST_AUX', 'S4F_EXTRA_DEFS') if os.environ.get(v)]
 if _DIAG and not os.environ.get('S4F_LIB_OUT'):
     # stamp / ablation builds compute wrong results by construction: they never overwrite the shipped library
     raise RuntimeError(f'{", ".join(_DIAG)} select a diagnostic build: set S4F_LIB_OUT=<path of the experiment library> as well')
