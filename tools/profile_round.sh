@@ -5,6 +5,12 @@ set -u
 out=$GRAFT_REPO_ROOT/$1; tag=$2
 mkdir -p "$out"; cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+echo "== HBM traffic of the GEMM family (two pmc passes) $(date +%T)"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$out/pmc_fetch" -- python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-parity-mode > "$out/pmc_fetch.log" 2>&1 || { tail -5 "$out/pmc_fetch.log"; exit 1; }
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$out/pmc_write" -- python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-parity-mode > "$out/pmc_write.log" 2>&1 || { tail -5 "$out/pmc_write.log"; exit 1; }
+ff=$(find "$out/pmc_fetch" -name '*counter_collection.csv' | head -1); fw=$(find "$out/pmc_write" -name '*counter_collection.csv' | head -1)
+python3 $R/tools/pmc_traffic.py "$ff" "$fw" "$out/${tag}_gemm_hbm_traffic.json" "$out/${tag}_hbm_traffic_by_kernel.txt" > /dev/null
+cp "$out/${tag}_gemm_hbm_traffic.json" $R/profiles/     # (the box's copy) so that the bench line below reports roofline.traffic of THESE kernel sources
 echo "== bench default $(date +%T)"
 python3 $R/bench.py --steps 20 --warmup 5 --timeline "$out/timeline_events.json" > "$out/bench.log" 2>&1 || { tail -5 "$out/bench.log"; exit 1; }
 tail -1 "$out/bench.log" > "$out/${tag}_bench_default.json"
@@ -19,11 +25,6 @@ db=$(find "$out/serial" -name '*.db' | head -1); [ -n "$db" ] && python3 $R/tool
 echo "== timeline (default streams) $(date +%T)"
 rocprofv3 --kernel-trace -d "$out/timeline" -- python3 $R/bench.py --steps 4 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-parity-mode > "$out/timeline.log" 2>&1 || { tail -5 "$out/timeline.log"; exit 1; }
 db=$(find "$out/timeline" -name '*.db' | head -1); [ -n "$db" ] && python3 $R/tools/timeline_report.py "$db" > "$out/${tag}_timeline_default.txt"
-echo "== HBM traffic of the GEMM family (two pmc passes) $(date +%T)"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d "$out/pmc_fetch" -- python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-parity-mode > "$out/pmc_fetch.log" 2>&1 || { tail -5 "$out/pmc_fetch.log"; exit 1; }
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d "$out/pmc_write" -- python3 $R/bench.py --steps 2 --warmup 3 --no-cpu-baseline --no-kernel-profile --no-parity-mode > "$out/pmc_write.log" 2>&1 || { tail -5 "$out/pmc_write.log"; exit 1; }
-ff=$(find "$out/pmc_fetch" -name '*counter_collection.csv' | head -1); fw=$(find "$out/pmc_write" -name '*counter_collection.csv' | head -1)
-python3 $R/tools/pmc_traffic.py "$ff" "$fw" "$out/${tag}_gemm_hbm_traffic.json" "$out/${tag}_hbm_traffic_by_kernel.txt" > /dev/null
 echo "== attention $(date +%T)"
 python3 $R/tools/attn_probe.py > "$out/${tag}_attention_probe.txt" 2>&1
 $R/tools/exp/pmc_attn.sh "$out/pmc_attn_fwd" attn > "$out/${tag}_pmc_attention_fwd.txt" 2>&1
