@@ -414,6 +414,11 @@ def main():
                     config=dict(workload=f'{args.workload}: {desc}', images_per_step_per_gpu=n_sup + n_unsup,
                                 crop=f'{img}x{img}', classes=ncls, parallelism=f'dp{world}', weights='random-init DeiT-B',
                                 teacher_conv_seg_gain=round(seg_gain, 2),
+                                pinned_by=('the pseudo-label CE on the plain mean-teacher branch is an extension flag (plain_mt_pseudo_loss; the '
+                                           'reference step yields no unsupervised loss there, SURVEY Q1): this flow is pinned against '
+                                           'the oracle on the tiny model (tests/test_step_gpu.py::test_plain_mt_pseudo_loss_vs_oracle); the '
+                                           'reference goldens full_pasa / full_semi4 / full_semi8_fwd cover a superset of its kernels at DeiT-B size')
+                                if flags.get('plain_mt_pseudo_loss') else 'reference goldens (tests/golden/full_*.npz)',
                                 dist_backend=dist.get_backend() if world > 1 else None,
                                 ranks_seen=dist.get_world_size() if world > 1 else 1,
                                 grad_collectives_per_step=round(grad_collectives, 2) if grad_collectives else None,
