@@ -30,7 +30,7 @@ python3 $R/tools/attn_probe.py > "$out/${tag}_attention_probe.txt" 2>&1
 $R/tools/exp/pmc_attn.sh "$out/pmc_attn_fwd" attn > "$out/${tag}_pmc_attention_fwd.txt" 2>&1
 $R/tools/exp/pmc_attn.sh "$out/pmc_attn_bwd" attnf > "$out/${tag}_pmc_attention_bwd.txt" 2>&1     # the one-sweep backward (round 4)
 echo "== other workloads $(date +%T)"
-for w in sup semi768; do python3 $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode 2>/dev/null | tail -1 > "$out/${tag}_bench_${w}.json"; done
+for w in sup semi768 ours; do python3 $R/bench.py --workload $w --steps 10 --warmup 3 --no-cpu-baseline --no-parity-mode 2>/dev/null | tail -1 > "$out/${tag}_bench_${w}.json"; done
 # keep the merged-back payload small: databases and raw traces stay on the box
 find "$out" -name '*.db' -delete; rm -rf "$out/stats" "$out/serial" "$out/timeline" "$out/pmc_fetch" "$out/pmc_write" "$out"/pmc_attn_*/p1 "$out"/pmc_attn_*/p2
 ls -la "$out"; echo done
