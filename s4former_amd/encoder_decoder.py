@@ -520,9 +520,10 @@ class EncoderDecoder(BaseSegmentor):
     # ---- the double-buffered teacher (EMA_DOUBLE): hooks called by S4FSGD on the stream of the update
     def _ema_pending_key(self, m):
         """what the pending update was computed from: any foreign write to the student or the teacher in between (load_state_dict,
-        a torch optimiser, an in-place edit) moves a version counter and the update is dropped for the in-place launch"""
+        a torch optimiser, an in-place edit - of a parameter OR of a BatchNorm running statistic; raw-pointer writers call
+        mark_dirty()) moves a version counter and the update is dropped for the in-place launch"""
         s, t = self._student_store, self._teacher_store
-        return (float(m), s.generation, t.generation, s._version_sum(), t._version_sum())
+        return (float(m), s.generation, t.generation, s._state_version_sum(), t._state_version_sum())
 
     def _ema_double_on(self):
         t = self._teacher_store

@@ -47,6 +47,7 @@ class ParamStore:
         self.group_ranges = {}       # group -> dict(params=(a,b), all=(a,b))
         self._versions = None
         self._shadow_dirty = True
+        self._dirty_marks = 0
         self.first_sgd_step = True
         self._collect()
 
@@ -223,9 +224,16 @@ class ParamStore:
     def _version_sum(self):
         return sum(self._tensor(e)._version for e in self.entries if e.is_param)
 
+    def _state_version_sum(self):
+        """like _version_sum, but over EVERY arena entry - the BatchNorm running statistics as well: what a pending
+        double-buffered teacher update must be keyed by (a buffer-only load_state_dict / reset_running_stats is a foreign write
+        too).  Writes through raw pointers do not move a version counter: they announce themselves with mark_dirty()."""
+        return sum(self._tensor(e)._version for e in self.entries) + self._dirty_marks
+
     def mark_dirty(self):
         self._shadow_dirty = True
         self._T_fresh = False
+        self._dirty_marks += 1
 
     # ------------------------------------------------------------------ transposed operand shadows (bf16 mode)
     def _T_rebuild_table(self):

@@ -131,6 +131,8 @@ pair(ln_bwd_f, wgrad)          # the first concurrent use of the second stream p
 for bn, bf in (('wgrad_grouped', wgrad), ('wgrad_one', wgrad_one), ('dgrad_fc1', dgrad_fc1), ('sgd', sgd)):
     tb = timed(bf)
     for an, af in (('ln_bwd', ln_bwd_f), ('ln_fwd', ln_fwd), ('cast', cast), ('colsum', colsum), ('dgrad_fc2', dgrad_fc2), ('attn_bwd', attn_bwd)):
+        if os.environ.get('CORUN_ONLY') and an not in os.environ['CORUN_ONLY'].split(','):
+            continue
         ta = timed(af)
         tp = min(pair(af, bf) for _ in range(2))
         print(f'{an:10s} {ta:7.1f} us + {bn:14s} {tb:7.1f} us = {ta + tb:7.1f} us serial, concurrent pair {tp:7.1f} us ({(ta + tb) / tp:5.2f}x)', flush=True)
