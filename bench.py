@@ -55,7 +55,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-profile', action='store_true')
     ap.add_argument('--no-parity-mode', action='store_true',
-                    help='skip the three extra steps in the fp32 parity mode (the numeric mode that meets the 1e-4 / bit-exact clause)')
+                    help='skip the secondary measurements behind the timed windows: the fp32 parity mode, the precise-teacher mode, the `ours` workload')
     ap.add_argument('--windows', type=int, default=3, help='timed windows of --steps steps each; the median window is reported')
     ap.add_argument('--timeline', default='', help='write the HIP-event timeline of the profiled step (no tracer attached) to this JSON file')
     ap.add_argument('--mask-ratio', type=float, default=0.5,
@@ -341,9 +341,55 @@ def main():
                 traffic_note = (f'{os.path.basename(tpath)} was measured on other GEMM kernel sources (sha {tj.get("kernel_src_sha")} '
                                 f'vs {kernel_src_sha()}): re-run tools/profile_round.sh; traffic not reported')
                 print('bench.py: STALE TRAFFIC PROFILE - ' + traffic_note, file=sys.stderr, flush=True)
+        # ---- what the event pairs can and cannot say.  The launches sit on 4 - 5 streams that overlap in time: the SUM of the GEMM
+        # durations can exceed the step (it did in round 5: 28.67 ms of GEMM events in a 28.26 ms step).  Reported beside it, from the
+        # same profiled step: the busy time of every stream (union of its launch intervals: each <= the step by construction) and the
+        # wall time during which at least one GEMM-family launch was running.
+        def union_ms(iv):
+            tot, end = 0.0, None
+            for a0, a1 in sorted(iv):
+                if end is None or a0 > end:
+                    tot, end = tot + (a1 - a0), a1
+                elif a1 > end:
+                    tot, end = tot + (a1 - end), a1
+            return tot
+        tl = prof.timeline()
+        by_stream, gemm_iv = {}, []
+        for name_, tag_, st_, t0_, d_ in tl:
+            g_ = name_ in ('s4f_gemm', 's4f_gemm_grouped')
+            q = by_stream.setdefault(st_, dict(all=[], gemm=[]))
+            q['all'].append((t0_, t0_ + d_))
+            if g_:
+                q['gemm'].append((t0_, t0_ + d_))
+                gemm_iv.append((t0_, t0_ + d_))
+        span = (max(t0_ + d_ for _, _, _, t0_, d_ in tl) - min(t0_ for _, _, _, t0_, _ in tl)) if tl else 0.0
+        queues = sorted((dict(busy_ms=round(union_ms(q['all']), 3), gemm_busy_ms=round(union_ms(q['gemm']), 3), launches=len(q['all']))
+                         for q in by_stream.values()), key=lambda d: -d['busy_ms'])
+        # ---- the same GEMM family from the round's rocprofv3 files (tools/profile_round.sh -> tools/gemm_time_profile.py), when they
+        # were measured on THESE kernel sources: under the tracer on the default streams, and alone on the chip (one stream)
+        traced = serial = None
+        gfiles = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_gemm_kernel_time.json')))
+        if args.workload == 'semi' and args.dtype == 'bf16' and gfiles:
+            sys.path.insert(0, os.path.join(ROOT, 'tools'))
+            from pmc_traffic import kernel_src_sha as _sha
+            gj = json.load(open(gfiles[-1]))
+            if gj.get('kernel_src_sha') == _sha():
+                src_ = 'profiles/' + os.path.basename(gfiles[-1])
+                traced = dict(achieved=round(gemm_gflop / gj['traced']['gemm_ms_per_step'], 1), frac=round(gemm_gflop / gj['traced']['gemm_ms_per_step'] / peak, 4),
+                              gemm_kernel_ms_per_step=round(gj['traced']['gemm_ms_per_step'], 3), source=src_ + ' (rocprofv3 --kernel-trace --stats of this command)')
+                serial = dict(achieved=round(gemm_gflop / gj['serial']['gemm_ms_per_step'], 1), frac=round(gemm_gflop / gj['serial']['gemm_ms_per_step'] / peak, 4),
+                              gemm_kernel_ms_per_step=round(gj['serial']['gemm_ms_per_step'], 3), step_ms_on_one_stream=gj['serial']['step_ms'],
+                              source=src_ + ' (the same step on ONE stream: every kernel alone on the chip)')
         roofline = dict(bound='mfma', kernel='s4f_gemm family: g2::gemm2_kernel / g5::gemm5_kernel / g6::gemm6_kernel (dense + implicit-GEMM conv, all launches of a step)',
                         achieved=round(gemm_gflop / gemm_ms, 1), peak=peak, unit='TFLOP/s',
                         frac=round(gemm_gflop / gemm_ms / peak, 4), traffic=traffic,
+                        gemm_event_ms_sum=round(gemm_ms, 3), gemm_wall_ms=round(union_ms(gemm_iv), 3), profiled_step_span_ms=round(span, 3),
+                        queues=queues, traced=traced, serial=serial,
+                        duration_note='achieved / frac = GEMM GFLOP / SUM of the per-launch HIP-event durations; the launches of different streams '
+                                      'overlap, so that sum (gemm_event_ms_sum) is a contention-inflated total and may exceed ms_per_step; queues[] = busy '
+                                      'time per stream of the same profiled step (each <= its span), gemm_wall_ms = time with at least one GEMM running; '
+                                      'traced / serial = the same family from the rocprofv3 files of this command',
+
                         traffic_source=('profiles/' + os.path.basename(tpath)) if traffic is not None else traffic_note,
                         algorithmic_gflop_per_launch=round(gemm_gflop / gemm_calls, 2),
                         launches_per_step=gemm_calls, avg_launch_ms=round(gemm_ms / gemm_calls, 4),
@@ -365,51 +411,109 @@ def main():
                                   'forward 4 B h N^2 64 flop, backward 8 B h N^2 64 (four products; the recomputed scores are not counted), '
                                   'durations from the same HIP-event pairs as roofline')
 
-    # ---- the numeric mode that meets north_star's parity clause (fp32 MFMA chain: losses 1e-4, pseudo-label masks equal outside
-    # the reference's tie set), timed on the SAME workload after the bf16 windows: what that clause costs, in the driver's record
-    parity_mode = None
-    if rank == 0 and world == 1 and args.dtype == 'bf16' and not args.no_parity_mode:
-        # (an auxiliary measurement: whatever goes wrong in here - out of memory on a smaller card, a failing launch - is
-        # recorded in the line and never costs the headline number that was measured above)
+    # ---- secondary measurements on the SAME box, after the timed windows (rank 0, one GPU): each builds its own model / optimizer,
+    # runs `warm` untimed + `nsteps` timed steps of the same step function, and is wrapped so that whatever goes wrong in it (out of
+    # memory on a smaller card, a failing launch) is recorded in the line and never costs the headline number measured above.
+    def fresh_run(workload, dtype_name, precise, warm, nsteps):
+        from s4former_amd import runtime as RT
+        n_sup_, n_unsup_, img_, ncls_, flags_, _ = WORKLOADS[workload]
+        S.set_compute_dtype(dtype_name)
+        RT.set_teacher_precise(precise)
         try:
-            del out
-            model = opt = sched = reducer = None
-            torch.cuda.empty_cache()
-            S.set_compute_dtype('fp32')
             torch.manual_seed(1999)
-            model = S.build_segmentor(setr_pup_model(img=img, num_classes=ncls, **flags))
-            model.init_weights()
-            model.train()
-            model.to(dev)
-            model.log_vars_as_tensors = True
-            opt = S.build_optimizer(model, dict(OPTIMIZER))
-            opt.fused_zero_grad = os.environ.get('S4F_FUSED_ZERO_GRAD', '1') != '0'
-            sched = S.PolyLR(opt, MAX_ITERS)
-            reducer = setup_data_parallel(model, opt, dev)
-            if n_unsup:
+            m_ = S.build_segmentor(setr_pup_model(img=img_, num_classes=ncls_, **flags_))
+            m_.init_weights()
+            m_.train()
+            m_.to(dev)
+            m_.log_vars_as_tensors = True
+            o_ = S.build_optimizer(m_, dict(OPTIMIZER))
+            o_.fused_zero_grad = os.environ.get('S4F_FUSED_ZERO_GRAD', '1') != '0'
+            sc_ = S.PolyLR(o_, MAX_ITERS)
+            r_ = setup_data_parallel(m_, o_, dev)
+            if n_unsup_:
                 with torch.no_grad():
-                    model.decode_head_ema.conv_seg.weight.mul_(seg_gain)      # the gain the bf16 teacher was calibrated to
-            for i in range(2):
-                step(i)
+                    m_.decode_head_ema.conv_seg.weight.mul_(seg_gain)      # the gain the bf16 teacher was calibrated to
+            bt_ = batches if (n_sup_, n_unsup_, img_, ncls_) == (n_sup, n_unsup, img, ncls) else \
+                [synthetic_batch(1999 + i, n_sup_, n_unsup_, img=img_, num_classes=ncls_, device=dev) for i in range(2)]
+
+            def one(i):
+                imgs_, gt_, metas_ = bt_[i % 2]
+                sc_.step(i)
+                o_.zero_grad()
+                out_ = m_.train_step(dict(img=imgs_, img_metas=metas_, gt_semantic_seg=gt_), o_, iter=i)
+                out_['loss'].backward()
+                join_side_streams()
+                r_.reduce_(m_.student_store.grad)
+                r_.wait()
+                o_.step(grad_scale=r_.grad_scale())
+                return out_
+            for i in range(warm):
+                one(i)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for i in range(3):
-                out = step(2 + i)
+            t0_ = time.perf_counter()
+            for i in range(nsteps):
+                out_ = one(warm + i)
             torch.cuda.synchronize()
-            pdt = (time.perf_counter() - t0) / 3
-            parity_mode = dict(dtype='fp32', ms_per_step=round(1e3 * pdt, 2), images_per_s=round((n_sup + n_unsup) / pdt, 2), steps=3, warmup=2,
-                               tflops=round(gflop_step / pdt / 1e3, 1), frac_of_fp32_mfma_peak=round(gflop_step / pdt / 1e3 / MFMA_PEAK_TFLOPS['fp32'], 4),
-                               mask_ratio=float(model.last_mask_ratio) if model.last_mask_ratio is not None else None,
+            sec = (time.perf_counter() - t0_) / nsteps
+            gf = step_gflop(n_sup_, n_unsup_, img=img_, num_classes=ncls_, pseudo_loss=True,
+                            student_passes=2 if flags_.get('attn_mask_seperate_head') else 1)
+            res = dict(ms_per_step=round(1e3 * sec, 2), images_per_s=round((n_sup_ + n_unsup_) / sec, 2), steps=nsteps, warmup=warm,
+                       tflops=round(gf / sec / 1e3, 1), gflop_per_step=round(gf, 1),
+                       mask_ratio=float(m_.last_mask_ratio) if m_.last_mask_ratio is not None else None,
+                       losses={k: round(float(v), 6) for k, v in out_['log_vars'].items()})
+            del m_, o_, sc_, r_, out_
+            torch.cuda.empty_cache()
+            return res
+        finally:
+            RT.set_teacher_precise(False)
+            S.set_compute_dtype(args.dtype)
+
+    def guarded(fn, *a):
+        try:
+            return fn(*a)
+        except Exception as e:      # noqa: BLE001
+            try:
+                torch.cuda.synchronize()
+            except Exception:       # noqa: BLE001
+                pass
+            return dict(error=f'{type(e).__name__}: {e}'[:300])
+
+    parity_mode = None
+    secondary = None
+    fused_zero_flag = bool(getattr(opt, 'fused_zero_grad', False))
+    stream_layout = getattr(reducer, 'stream_layout', None) if world > 1 else None
+    if rank == 0 and world == 1 and args.dtype == 'bf16' and not args.no_parity_mode:
+        del out
+        model = opt = sched = reducer = None
+        torch.cuda.empty_cache()
+        # (a) the numeric mode that meets north_star's parity clause on every count (fp32 MFMA chain: losses 1e-4, pseudo-label masks
+        # equal outside the reference's tie set), timed on the SAME workload: what that clause costs
+        parity_mode = guarded(fresh_run, args.workload, 'fp32', False, 2, 3)
+        if 'error' not in parity_mode:
+            parity_mode.update(dtype='fp32', frac_of_fp32_mfma_peak=round(parity_mode['tflops'] / MFMA_PEAK_TFLOPS['fp32'], 4),
                                note='same workload in the fp32 parity mode (v_mfma_f32_16x16x4_f32 chains, fp32 everything): the mode whose losses '
                                     'meet the goldens of the reference to 1e-4 and whose pseudo-label masks differ from it only inside its tie set '
                                     '(tests/test_fullsize_gpu.py); value / ms_per_step above are the bf16 perf mode')
-            S.set_compute_dtype(args.dtype)
-        except Exception as e:      # noqa: BLE001
-            parity_mode = dict(error=f'{type(e).__name__}: {e}'[:300])
-            try:
-                S.set_compute_dtype(args.dtype)
-            except Exception:       # noqa: BLE001
-                pass
+        # (b) round 6, the PRECISE TEACHER (S4F_TEACHER_PRECISE=1): student bf16, teacher pass on the fp32 parity kernels - the
+        # pseudo-label masks and PASA confidences are then the parity mode's (reference: encoder_decoder.py:888-901 is fp32)
+        if n_unsup:
+            tp = guarded(fresh_run, args.workload, 'bf16', True, 3, 5)
+            if 'error' not in tp:
+                tp.update(dtype='bf16 student + fp32 teacher', switch='S4F_TEACHER_PRECISE=1',
+                          parity='pseudo-labels equal to the reference outside its tie set (8 of 2,097,152 on cfg3\'s own batch, all inside), named '
+                                 'losses of the first iteration within 1e-4 (6.8e-5 / 9.1e-5): tests/test_fullsize_gpu.py::'
+                                 'test_precise_teacher_gives_the_reference_pseudo_labels_in_the_bf16_mode, profiles/r06_parity_report.json')
+            parity_mode['teacher_precise'] = tp
+        # (c) the one reference config that reaches compute_pseudo_loss as written (configs/setr/..._MT_w_ours.py:236-256: PASA with its
+        # masked AND plain student pass, CutMix / PatchShuffle, NCR): `--workload ours`, pinned at DeiT-B size by tests/golden/full_ours.npz
+        if args.workload == 'semi':
+            secondary = guarded(fresh_run, 'ours', 'bf16', False, 3, 10)
+            if 'error' not in secondary:
+                secondary.update(workload='ours: ' + WORKLOADS['ours'][5], dtype='bf16',
+                                 frac_of_bf16_mfma_peak=round(secondary['tflops'] / MFMA_PEAK_TFLOPS['bf16'], 4),
+                                 pinned_by='tests/golden/full_ours.npz (the reference\'s own code, two iterations at DeiT-B size): '
+                                           'tests/test_fullsize_gpu.py::test_fullsize_step_vs_reference_golden[full_ours-fp32|bf16]; measured margins '
+                                           'in profiles/r06_parity_report.json (deit_b/full_ours/*)')
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -434,9 +538,9 @@ def main():
                                 dist_backend=dist.get_backend() if world > 1 else None,
                                 ranks_seen=dist.get_world_size() if world > 1 else 1,
                                 grad_collectives_per_step=round(grad_collectives, 2) if grad_collectives else None,
-                                fused_zero_grad=bool(getattr(opt, 'fused_zero_grad', False)),
-                                stream_layout=getattr(reducer, 'stream_layout', None) if world > 1 else None),
-                    roofline=roofline, attention=attention, parity_mode=parity_mode, cpu_baseline=cpu, losses=losses, mask_ratio=mask_ratio,
+                                fused_zero_grad=fused_zero_flag,
+                                stream_layout=stream_layout),
+                    roofline=roofline, attention=attention, parity_mode=parity_mode, secondary=secondary, cpu_baseline=cpu, losses=losses, mask_ratio=mask_ratio,
                     host_enqueue_ms_per_step=round(1e3 * host_dt / args.steps, 3),
                     host_enqueue_idle_queue_ms=round(host_idle_ms, 3))
         if kprof is not None:

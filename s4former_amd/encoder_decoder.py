@@ -322,7 +322,7 @@ class EncoderDecoder(BaseSegmentor):
         self._student_store.ensure_grads()
         self._student_store.sync_shadow()
         if self._teacher_store is not None:
-            self._teacher_store.ensure(device, code)
+            self._teacher_store.ensure(device, runtime.teacher_dtype())
             self._teacher_store.sync_shadow()
         return self._student_store, self._teacher_store
 

@@ -42,3 +42,26 @@ def set_residual_fp32(flag):
 def residual_dtype():
     """S4F_BF16 or S4F_F32: the `xdtype` argument of the C ABI"""
     return BF16 if (_code == BF16 and not _resid_fp32) else F32
+
+
+# Round 6 - the PRECISE TEACHER (S4F_TEACHER_PRECISE=1 / set_teacher_precise(True)): the teacher pass (backbone_ema + decode_head_ema:
+# no gradients, 12.6 % of the step's flop) runs on the fp32 parity kernels (v_mfma_f32_16x16x4_f32 chains, fp32 activations) while the
+# student keeps the bf16 perf mode.  The reference forms softmax / max / `> threshold` in fp32 (encoder_decoder.py:888-901); with bf16
+# teacher activations 0.7 - 1.3 % of the pseudo-label entries sit on the other side of the 0.95 threshold (no argmax flips), with the
+# fp32 teacher the pseudo-label masks and the PASA confidences are the parity mode's: equal to the reference's outside its tie set.
+# The teacher's ParamStore simply takes dtype F32 (its kernels read store.dtype); the EMA writes no bf16 shadow for it.
+_teacher_precise = os.environ.get('S4F_TEACHER_PRECISE', '0') not in ('0', '')
+
+
+def set_teacher_precise(flag):
+    global _teacher_precise
+    _teacher_precise = bool(flag)
+
+
+def teacher_precise():
+    return _teacher_precise
+
+
+def teacher_dtype():
+    """numeric mode of the teacher's ParamStore: the compute dtype, or F32 under the precise-teacher switch"""
+    return F32 if _teacher_precise else _code
