@@ -223,6 +223,21 @@ def main():
     for _ in range(args.warmup):
         out = step(it)
         it += 1
+    schedule = None
+    if world > 1:
+        # round 6: the N > 1 schedule knobs (head lockstep, gradient bucket size) rest on one-rank evidence - they are timed on THIS
+        # job's ranks here, untimed for the benchmark, and the fastest setting is kept (dist.autotune_schedule; every setting is
+        # parity-tested at world 2).  The first three steps of the run (the warm-up's) have checked their flush order across the ranks.
+        from s4former_amd.dist import autotune_schedule
+        state_it = [it]
+
+        def _tune_step():
+            step(state_it[0])
+            state_it[0] += 1
+        schedule = autotune_schedule(model, reducer, _tune_step, steps=int(os.environ.get('S4F_AUTOTUNE_STEPS', '10')))
+        it = state_it[0]
+        if rank == 0 and schedule is not None:
+            print('bench.py: N > 1 schedule by measurement:', json.dumps(schedule), file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -263,6 +278,15 @@ def main():
         from s4former_amd.functional import check_stream_layout
         print('[layout]', os.environ.get('S4F_PRETOUCH', '-'), f'{dt / args.steps * 1e3:.3f} ms/step',
               check_stream_layout(dev, extra=[('opt', getattr(opt, '_stream', None))]), file=sys.stderr, flush=True)
+    # ---- per-collective latency of the gradient exchange (N > 1): two more steps with an event pair around every all-reduce
+    coll = None
+    if world > 1:
+        reducer.timing = True
+        for _ in range(2):
+            step(it)
+            it += 1
+        reducer.timing = False
+        coll = reducer.latency_summary()
     # ---- host cost of one step, measured from an IDLE device (nothing queued: no back-pressure from a full HIP queue in it);
     # host_enqueue_ms_per_step above is the average inside the timed region, where submits can block on the queue
     torch.cuda.synchronize()
@@ -538,6 +562,8 @@ def main():
                                 dist_backend=dist.get_backend() if world > 1 else None,
                                 ranks_seen=dist.get_world_size() if world > 1 else 1,
                                 grad_collectives_per_step=round(grad_collectives, 2) if grad_collectives else None,
+                                grad_collective_latency=coll, schedule=schedule,
+                                flush_order_checked_steps=(int(os.environ.get('S4F_CHECK_FLUSH', '3') or 0) if world > 1 else None),
                                 fused_zero_grad=fused_zero_flag,
                                 stream_layout=stream_layout),
                     roofline=roofline, attention=attention, parity_mode=parity_mode, secondary=secondary, cpu_baseline=cpu, losses=losses, mask_ratio=mask_ratio,

@@ -118,13 +118,21 @@ def check_stream_layout(device, cycles=400_000, extra=()):
             return e0.elapsed_time(e1)
         timed([names[0][1]])                                  # warm-up
         one = min(timed([names[0][1]]) for _ in range(3))
+        # `ok` judges only the pairs the first-use order is MEANT to separate: the four compute streams among themselves and the
+        # communication stream against the chain.  With more streams than the runtime has hardware queues (four) SOME pair shares a
+        # queue by pigeonhole: the remaining pairs (comm / opt against the head and weight-gradient streams) are reported, not judged.
+        core = {'main', 'decode', 'aux', 'side'}
         ok = True
         for i in range(len(names)):
             for j in range(i + 1, len(names)):
                 t = min(timed([names[i][1], names[j][1]]) for _ in range(2))
                 r = t / max(one, 1e-6)
                 res['pairs'][f'{names[i][0]}+{names[j][0]}'] = round(r, 2)
-                ok = ok and r < 1.5
+                judged = ({names[i][0], names[j][0]} <= core) or ({names[i][0], names[j][0]} == {'main', 'comm'})
+                if judged:
+                    ok = ok and r < 1.5
+                else:
+                    res.setdefault('informational', []).append(f'{names[i][0]}+{names[j][0]}')
         res['ok'] = ok
     except Exception as e:                                    # noqa: BLE001 - a missing _sleep or an odd runtime: no claim, fall back
         res['error'] = f'{type(e).__name__}: {e}'

@@ -135,9 +135,25 @@ class S4FSGD(torch.optim.Optimizer):
                                store.first_sgd_step, store.dtype, zero_grad=self.fused_zero_grad)
             store.sync_T_range(a, b)                 # the transposed operand shadows of this range, behind its update
             hook = getattr(self.model, '_ema_behind_update', None)
-            if hook is not None:                     # round 5: the teacher's NEXT value of this range, into its second arena
+            if hook is not None and not (handle is not None and reducer._stream is not None):
+                # round 5: the teacher's NEXT value of this range, into its second arena
                 for lo, hi, _ in pieces:
                     hook(lo, hi)
+            ema_ev = None
+            if hook is not None and handle is not None and reducer._stream is not None:
+                ema_ev = torch.cuda.Event()
+                ema_ev.record()
+        if ema_ev is not None:
+            # Round 6 (N > 1): NOT on the communication stream - the next bucket's all-reduce is queued there and would wait behind
+            # 3 fp32 arenas + the bf16 shadow of EMA traffic per range.  The out-of-place EMA runs on the optimiser's own stream
+            # behind an event recorded after this range's SGD; step() joins that stream before the pending update is published.
+            if self._stream is None:
+                self._stream = torch.cuda.Stream()
+            self._stream.wait_event(ema_ev)
+            with torch.cuda.stream(self._stream):
+                for lo, hi, _ in pieces:
+                    hook(lo, hi)
+            self._eager_done.append((pieces[0][0], pieces[0][0], self._stream))      # (empty range: only the stream is joined)
         for lo, hi, _ in pieces:
             self._eager_done.append((lo, hi, stream))
 

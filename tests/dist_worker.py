@@ -31,6 +31,8 @@ def main():
     ap.add_argument('--n-unsup', type=int, default=4)
     ap.add_argument('--iters', type=int, default=2)
     ap.add_argument('--watchdog', type=int, default=90)
+    ap.add_argument('--autotune', action='store_true',
+                    help='after the recorded steps: dist.autotune_schedule (the N > 1 schedule picked by measurement), then the replica check again')
     ap.add_argument('--rccl-one-rank', action='store_true',
                     help='a process group of ONE rank over backend nccl (= RCCL) with every collective of the data path forced on')
     args = ap.parse_args()
@@ -131,6 +133,37 @@ def main():
     rec['teacher_sha'] = np.array(hashlib.sha256(model.teacher_store.flat.cpu().numpy().tobytes()).hexdigest())
     rec['mom_sha'] = np.array(hashlib.sha256(model.student_store.mom.cpu().numpy().tobytes()).hexdigest())
     rec['nbt'] = np.array([int(v) for k, v in sd.items() if k.endswith('num_batches_tracked')])
+    if args.autotune:
+        # round 6: the warm-up auto-selection of the N > 1 schedule (head lockstep, bucket size) on this very model, every rank the
+        # same number of steps; afterwards the replicas must still be bit-identical and agree on what was chosen
+        from s4former_amd.dist import autotune_schedule
+        state = dict(it=args.iters)
+
+        def run_step():
+            it = state['it']
+            state['it'] += 1
+            imgs, gt, metas = C.make_batch(4242 + it % 2, ns, nu)
+            idx = list(range(rank * a, (rank + 1) * a)) + [ns + i for i in range(rank * b, (rank + 1) * b)] + \
+                [ns + nu + i for i in range(rank * b, (rank + 1) * b)]
+            imgs, gt, metas = imgs[idx].to(dev), gt[idx].to(dev), [metas[i] for i in idx]
+            sched.step(it)
+            opt.zero_grad()
+            out = model.train_step(dict(img=imgs, img_metas=metas, gt_semantic_seg=gt), opt, iter=it)
+            out['loss'].backward()
+            join_side_streams()
+            reducer.reduce_(model.student_store.grad)
+            reducer.wait()
+            opt.step(grad_scale=reducer.grad_scale())
+            state['loss'] = float(out['loss'])
+        sch = autotune_schedule(model, reducer, run_step, steps=2)
+        torch.cuda.synchronize()
+        rec['schedule'] = np.array(json.dumps(sch))
+        rec['tuned_steps'] = np.int64(state['it'] - args.iters)
+        rec['tuned_last_loss'] = np.float64(state.get('loss', float('nan')))
+        rec['tuned_student_sha'] = np.array(hashlib.sha256(model.student_store.flat.cpu().numpy().tobytes()).hexdigest())
+        rec['tuned_teacher_sha'] = np.array(hashlib.sha256(model.teacher_store.flat.cpu().numpy().tobytes()).hexdigest())
+        rec['tuned_mom_sha'] = np.array(hashlib.sha256(model.student_store.mom.cpu().numpy().tobytes()).hexdigest())
+        rec['check_steps_left'] = np.int64(reducer.check_steps)
     rec['issued'] = np.array([issued['grad'], issued['bn']])
     rec['stream_layout'] = np.array(json.dumps(getattr(reducer, 'stream_layout', None)))
     rec['meta'] = np.array(json.dumps(dict(world=world, rank=rank, backend=dist.get_backend() if dist.is_initialized() else None,

@@ -110,6 +110,7 @@ VARIANTS = {
     'default': {},
     'no_eager_sgd': dict(S4F_EAGER_SGD='0'),
     'lockstep_heads': dict(S4F_AUX_LOCKSTEP='1', S4F_DECODE_LOCKSTEP='1'),
+    'lockstep_aux_only': dict(S4F_AUX_LOCKSTEP='1', S4F_DECODE_LOCKSTEP='0'),       # (round 6: a setting autotune_schedule may pick)
     # round 3: final ranges merged two tiny layers at a time (the production size merges three DeiT-B layers), and the round-2
     # schedule (one collective per range).  Round 4: the head lockstep is opt-in again (the default runs one head after the other);
     # the empirical first-use order of the streams has its own switch
@@ -120,7 +121,7 @@ VARIANTS = {
 
 
 @pytest.mark.parametrize('variant,flags', [('default', 'pasa'), ('default', 'plain'), ('no_eager_sgd', 'pasa'),
-                                           ('lockstep_heads', 'pasa'), ('coalesced_buckets', 'pasa'),
+                                           ('lockstep_heads', 'pasa'), ('lockstep_aux_only', 'plain'), ('coalesced_buckets', 'pasa'),
                                            ('round2_schedule', 'plain'), ('natural_stream_order', 'plain')])
 def test_two_ranks_equal_one_rank_on_the_concatenated_batch(variant, flags, single, tmp_path):
     d = str(tmp_path)
@@ -151,6 +152,54 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(variant, flags, sing
             msgs.append(f'state {k}: |.|_1 {got:.7f} vs {want:.7f}, sum {gs:.7f} vs {ws:.7f}')
     assert np.array_equal(r0['nbt'], ref['nbt'])
     assert not msgs, '\n'.join(msgs[:20])
+
+
+def test_two_ranks_pick_their_schedule_by_measurement_and_check_their_first_steps(single, tmp_path):
+    """Round 6 (reference: the one fixed DDP schedule of mmseg/apis/train.py:129-138).  (1) The first steps of a multi-rank run
+    verify, before every gradient collective, that all ranks are about to reduce the same span (GradReducer.check_steps, default
+    3): the two recorded steps run under that check and must still equal the one-rank run.  (2) dist.autotune_schedule times the
+    head-lockstep settings and two bucket sizes on the job's own ranks and keeps the fastest: every candidate is timed, both
+    ranks keep the SAME setting, and the replicas are still bit-identical after the tuning steps.  Each setting it may pick is
+    held against the one-rank run by the variants above (default, lockstep_aux_only, lockstep_heads, coalesced_buckets)."""
+    d = str(tmp_path)
+    _run_ranks(2, 29650, [WORKER, '--out', d, '--flags', 'plain', '--autotune'], _env(), d)
+    r0, r1, ref = _load(d, 0), _load(d, 1), single['plain']
+    for it in range(2):
+        assert np.allclose(r0[f'it{it}_loss_vals'], ref[f'it{it}_loss_vals'], rtol=1e-5, atol=1e-7), it
+    s0, s1 = json.loads(str(r0['schedule'])), json.loads(str(r1['schedule']))
+    assert s0 == s1, (s0, s1)                                        # the ranks agreed (MAX over ranks per candidate)
+    assert {'lockstep=off', 'lockstep=aux', 'lockstep=aux+decode'} <= set(s0) and sum(k.startswith('bucket_min_elems=') for k in s0) == 2, s0
+    assert s0['chosen']['lockstep'] in ('off', 'aux', 'aux+decode') and s0['chosen']['bucket_min_elems'] > 0
+    assert all(v > 0 for k, v in s0.items() if k != 'chosen')
+    assert int(r0['tuned_steps']) == int(r1['tuned_steps']) == 5 * 3            # 5 candidates x (1 untimed + 2 timed) steps
+    for k in ('tuned_student_sha', 'tuned_mom_sha', 'tuned_teacher_sha'):
+        assert str(r0[k]) == str(r1[k]), f'{k} differs between the ranks after the tuning steps'
+    assert np.isfinite(float(r0['tuned_last_loss']))
+    assert int(r0['check_steps_left']) == 0                          # the three checked steps are behind us
+
+
+def test_a_divergent_flush_order_is_reported_not_hung(tmp_path):
+    """the check itself: two ranks that hand DIFFERENT spans to the reducer as their first collective get an S4FError naming both
+    spans (tests/dist_worker.py is not involved: a bare GradReducer over a flat tensor, gloo)"""
+    d = str(tmp_path)
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "from s4former_amd.dist import GradReducer, init_distributed\n"
+        "from s4former_amd._lib import S4FError\n"
+        "rank, local, world = init_distributed(timeout_s=30)\n"
+        "g = torch.ones(4096, device='cuda')\n"
+        "r = GradReducer()\n"
+        "a, b = (0, 1024) if rank == 0 else (1024, 2048)\n"
+        "try:\n"
+        "    r._launch(g[a:b], (a, b))\n"
+        "    r.wait()\n"
+        "    print('NO-ERROR')\n"
+        "except S4FError as e:\n"
+        "    print('CAUGHT', 'DIFFERENT spans' in str(e), flush=True)\n"
+        "dist.barrier()\n" % ROOT)
+    outs = _run_ranks(2, 29652, ['-c', code], _env(), d)
+    assert all('CAUGHT True' in o for o in outs), outs
 
 
 def test_two_ranks_bf16_replicas_stay_identical(tmp_path):
@@ -198,7 +247,7 @@ def test_bench_two_ranks_gloo(tmp_path):
     """bench.py's own N > 1 control flow (rank-symmetric profiled step, rank-0-only reporting, barriers) on the tiny workload,
     launched exactly as the driver launches it (python -m torch.distributed.run)"""
     d = str(tmp_path)
-    env = _env(S4F_BENCH_WATCHDOG='90', S4F_WATCHDOG_DIR=d, S4F_DIST_TIMEOUT_S='60')
+    env = _env(S4F_BENCH_WATCHDOG='90', S4F_WATCHDOG_DIR=d, S4F_DIST_TIMEOUT_S='60', S4F_AUTOTUNE_STEPS='2')
     r = _run(_torchrun(2, 29630, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
                                   '--workload', 'tiny', '--no-cpu-baseline']), env, d)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
@@ -207,4 +256,8 @@ def test_bench_two_ranks_gloo(tmp_path):
     assert out['n_gpus'] == 2 and out['value'] > 0 and out['roofline'] is not None
     assert out['config']['dist_backend'] == 'gloo' and out['config']['ranks_seen'] == 2
     assert 'pairs' in (out['config']['stream_layout'] or {}), out['config']
+    # round 6: the schedule picked by measurement during warm-up and the per-collective latency are in the line
+    assert out['config']['schedule'] and out['config']['schedule']['chosen'], out['config']
+    assert out['config']['grad_collective_latency']['collectives'] >= 2, out['config']
+    assert out['config']['flush_order_checked_steps'] == 3
     assert abs(out['losses']['loss']) < 1e3
