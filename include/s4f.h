@@ -180,6 +180,18 @@ int s4f_attention_bwd(const void* qkv, const void* ctx, const void* dctx, const 
  * side path of the pre / slab passes.  ws: workspace of at least s4f_attention_bwd_ws_bytes(B, N, H) bytes, 256-byte aligned,
  * contents undefined on entry and exit.  Other arguments as s4f_attention_bwd. */
 int64_t s4f_attention_bwd_ws_bytes(int B, int N, int H);
+/* Round 6 - SURVEY §8(b)'s generic workspace query: bytes of caller-owned scratch an entry point needs for the given extents (0 = none,
+ * -1 = unknown op / wrong number of extents).  The library never allocates: every buffer below is a torch tensor of the host layer.
+ *   S4F_WS_ATTENTION_BWD   dims = {B, N, H}   the fp32 dQ slabs + delta / cls-key partials of s4f_attention_bwd_fused (256-byte aligned)
+ *   S4F_WS_BN_SUMS         dims = {C}         the 2 C fp32 sums a BatchNorm statistics pass fills (s4f_bn_stats, colstats of s4f_gemm;
+ *                                             the buffer that crosses the ranks under SyncBN)
+ *   S4F_WS_GEMM_SPLITK     dims = {M, N}      the zero-initialised fp32 output a split-K launch accumulates into by atomics
+ *                                             (s4f_gemm with atomic = 1: the small-stage convs, weight gradients go straight to the arena)
+ * replaces: nothing in the reference (ATen allocates its workspaces itself); SURVEY §8(b) lists the symbol. */
+#define S4F_WS_ATTENTION_BWD 1
+#define S4F_WS_BN_SUMS 2
+#define S4F_WS_GEMM_SPLITK 3
+int64_t s4f_workspace_bytes(int op, const int64_t* dims, int ndims);
 int s4f_attention_bwd_fused(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta,
                             void* dqkv, const float* bias_u, const float* row_flag, float bias_w, int B, int N,
                             int H, void* ws, int64_t ws_bytes, s4f_stream stream);

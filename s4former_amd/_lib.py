@@ -81,6 +81,7 @@ _SIGS = {
     's4f_attention_bwd': [c_void_p] * 8 + [c_float, c_int, c_int, c_int, c_int, c_void_p],
     's4f_attention_bwd_fused': [c_void_p] * 8 + [c_float, c_int, c_int, c_int, c_void_p, c_int64, c_void_p],
     's4f_attention_bwd_ws_bytes': [c_int, c_int, c_int],
+    's4f_workspace_bytes': [c_int, c_void_p, c_int],
     's4f_bn_stats': [c_void_p, c_int64, c_int, c_void_p, c_int, c_void_p],
     's4f_bn_finalize': [c_void_p, c_double, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_float, c_int,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
@@ -118,7 +119,7 @@ _SIGS = {
     's4f_sgd_momentum': [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_int, c_int,
                          c_void_p],
 }
-_RESTYPES = {'s4f_attention_bwd_ws_bytes': c_int64}     # everything else returns the int status
+_RESTYPES = {'s4f_attention_bwd_ws_bytes': c_int64, 's4f_workspace_bytes': c_int64}     # everything else returns the int status
 EXPORTED_SYMBOLS = sorted(list(_SIGS) + ['s4f_last_error', 's4f_version'])
 
 

@@ -811,6 +811,16 @@ S4F_API int64_t s4f_attention_bwd_ws_bytes(int B, int N, int H) {
   return al256((int64_t)B * H * N * 4) + al256((int64_t)B * H * nchunk * 128 * 4) + al256(nkb * (int64_t)B * N * H * 64 * 4);
 }
 
+S4F_API int64_t s4f_workspace_bytes(int op, const int64_t* dims, int ndims) {
+  if (!dims) return -1;
+  switch (op) {
+    case S4F_WS_ATTENTION_BWD: return ndims == 3 ? s4f_attention_bwd_ws_bytes((int)dims[0], (int)dims[1], (int)dims[2]) : -1;
+    case S4F_WS_BN_SUMS: return ndims == 1 && dims[0] > 0 ? 2 * dims[0] * 4 : -1;
+    case S4F_WS_GEMM_SPLITK: return ndims == 2 && dims[0] > 0 && dims[1] > 0 ? dims[0] * dims[1] * 4 : -1;
+    default: return -1;
+  }
+}
+
 S4F_API int s4f_attention_bwd_fused(const void* qkv, const void* ctx, const void* dctx, const float* lse, float* delta,
                                     void* dqkv, const float* bias_u, const float* row_flag, float bias_w, int B, int N,
                                     int H, void* ws, int64_t ws_bytes, s4f_stream stream) {

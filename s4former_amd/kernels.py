@@ -12,7 +12,7 @@ from ._lib import (ACT_COLSTATS, ACT_GELU, ACT_GELU_BWD, ACT_NONE, BF16, F32, OP
                    OP_ROW_CONV, S4FError, call, p, stream)
 
 __all__ = ['gemm', 'wgrad_grouped', 'transpose_many', 'cast', 'cast_back', 'im2col_patch16', 'cls_pos', 'tokens_bwd', 'colsum', 'layernorm_fwd',
-           'layernorm_bwd', 'add_f32', 'attention_fwd', 'attention_bwd', 'attention_bwd_fused', 'attention_bwd_ws_bytes', 'bn_stats', 'bn_finalize',
+           'layernorm_bwd', 'add_f32', 'attention_fwd', 'attention_bwd', 'attention_bwd_fused', 'attention_bwd_ws_bytes', 'workspace_bytes', 'bn_stats', 'bn_finalize',
            'bn_relu_up_fwd', 'bn_relu_up_bwd', 'bn_bwd_apply', 'bn_param_grads', 'upce_fwd', 'upce_bwd',
            'up_pseudo_label', 'up_logits_nchw', 'ce_fwd', 'ce_bwd', 'ema', 'sgd_momentum', 'ncr_fwd', 'ncr_bwd', 'mix_images',
            'cutmix_labels', 'gather_rows', 'pasa_patch_u', 'resize_bilinear', 'softmax_argmax', 'confusion_counts']
@@ -474,8 +474,21 @@ def attention_bwd(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, dtype, bias_u=None,
          H, dtype, stream(), tag=('attn', B, N, H))
 
 
+WS_ATTENTION_BWD, WS_BN_SUMS, WS_GEMM_SPLITK = 1, 2, 3
+
+
+def workspace_bytes(op, *dims):
+    """s4f_workspace_bytes: bytes of caller-owned scratch for `op` at the given extents; raises on an unknown op"""
+    import ctypes
+    arr = (ctypes.c_int64 * len(dims))(*[int(d) for d in dims])
+    n = int(L.load().s4f_workspace_bytes(int(op), arr, len(dims)))
+    if n < 0:
+        raise S4FError(f's4f_workspace_bytes: unknown op {op} or wrong extents {dims}')
+    return n
+
+
 def attention_bwd_ws_bytes(B, N, H):
-    return int(L.load().s4f_attention_bwd_ws_bytes(B, N, H))
+    return workspace_bytes(WS_ATTENTION_BWD, B, N, H)
 
 
 def attention_bwd_fused(qkv, ctx, dctx, lse, delta, dqkv, B, N, H, ws, bias_u=None, row_flag=None, bias_w=0.0):

@@ -138,3 +138,18 @@ def test_shipped_tuning_table_is_well_formed():
             assert N % 256 == 0 or a_mode == 1, (k, v)       # 256-wide tiles
         if hint in (8, 9):
             assert N % 192 == 0, (k, v)
+
+
+def test_generic_workspace_query_of_the_c_abi():
+    """s4f_workspace_bytes(op, extents) - a pure host function of the library (no device needed): the attention
+    backward's scratch equals the dedicated query, the BatchNorm sums are 2 C floats, a split-K output is M x N floats, an
+    unknown op / a wrong number of extents is an error (return -1 -> S4FError in the binding)."""
+    from s4former_amd import _lib
+    from s4former_amd import kernels as K
+    lib = _lib.load()
+    assert K.workspace_bytes(K.WS_ATTENTION_BWD, 16, 1025, 12) == int(lib.s4f_attention_bwd_ws_bytes(16, 1025, 12)) > 200_000_000
+    assert K.workspace_bytes(K.WS_BN_SUMS, 256) == 2 * 256 * 4
+    assert K.workspace_bytes(K.WS_GEMM_SPLITK, 8192, 256) == 8192 * 256 * 4
+    for bad in ((99, 1), (K.WS_BN_SUMS, 1, 2), (K.WS_ATTENTION_BWD, 16, 1025)):
+        with pytest.raises(_lib.S4FError):
+            K.workspace_bytes(*bad)
