@@ -625,8 +625,7 @@ S4F_API int s4f_layernorm_bwd(const void* dy, const void* x, const float* mean, 
   S4F_CHECK(rows_per_img > 0, "s4f_layernorm_bwd: rows_per_img must be > 0");
   const long bstride = (long)in_batch_stride;
   int grid = grid_for(rows, 16);   // 4 rows per wave: fewer atomics on dgamma/dbeta
-  static const int grid_cap = [] { const char* e = getenv("S4F_LN_BWD_GRID"); return e && atoi(e) > 0 ? atoi(e) : 512; }();
-  if (grid > grid_cap) grid = grid_cap;
+  if (grid > 512) grid = 512;
   if (xdtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, bf16_t, (const bf16_t*)dy, (const bf16_t*)x, mean, rstd, gamma, (const bf16_t*)dresid, (bf16_t*)dx, (bf16_t*)nullptr, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
   else if (dtype == S4F_BF16) { LN_DISPATCH(ln_bwd_kernel, bf16_t, float, (const bf16_t*)dy, (const float*)x, mean, rstd, gamma, (const float*)dresid, (float*)dx, (bf16_t*)dx_t, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
   else { LN_DISPATCH(ln_bwd_kernel, float, float, (const float*)dy, (const float*)x, mean, rstd, gamma, (const float*)dresid, (float*)dx, (float*)dx_t, dgamma, dbeta, dcolsum, rows, rows_per_img, bstride, accumulate) }
