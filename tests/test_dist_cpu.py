@@ -164,3 +164,60 @@ def test_world_gloo(world):
     assert torch.allclose(out[0]['bn'][1], xc.var(0, unbiased=False), atol=1e-4 * world)
     for r in range(1, world):
         assert torch.equal(out[0]['bn'][0], out[r]['bn'][0])
+
+
+def _diverge_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from s4former_amd._lib import S4FError
+    from s4former_amd.dist import GradReducer, init_distributed
+    init_distributed(backend='gloo', timeout_s=60)
+    g = torch.ones(4096)
+    res = {}
+    # (1) the same span on every rank: checked, reduced, one checked step used up
+    red = GradReducer(side_stream=False)
+    assert red.check_steps == 3
+    red._launch(g[0:1024], (0, 1024))
+    red.wait()
+    res['same'] = (float(g[0]), red.check_steps)
+    # (2) another span on the last rank: every rank gets the error BEFORE the collective is issued (no hang, no wrong sum)
+    a, b = (1024, 2048) if rank < world - 1 else (2048, 3072)
+    try:
+        red._launch(g[a:b], (a, b))
+        res['diverged'] = 'no error'
+    except S4FError as e:
+        res['diverged'] = ('DIFFERENT spans' in str(e), str([0, a, b, 1]) in str(e))
+    res['untouched'] = float(g[1024:3072].sum())
+    # (3) S4F_CHECK_FLUSH = 0 steps: nothing is exchanged beside the collective itself
+    red0 = GradReducer(side_stream=False)
+    red0.check_steps = 0
+    red0._launch(g[3072:4096], (3072, 4096))
+    red0.wait()
+    res['unchecked'] = float(g[3072])
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_a_divergent_flush_order_raises_on_every_rank(world):
+    """round 6, GradReducer.check_steps (reference: the fixed bucket order of the DDP wrap, mmseg/apis/train.py:129-138): in the
+    first steps of a multi-rank run the ranks exchange the span they are about to all-reduce; a rank with ANOTHER span makes every
+    rank raise an S4FError that names the spans - before the mismatched collective is issued"""
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_diverge_worker, args=(r, world, port, q)) for r in range(world)]
+    for p_ in procs:
+        p_.start()
+    out = {}
+    for _ in range(world):
+        r, res = q.get(timeout=120)
+        out[r] = res
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    for r in range(world):
+        assert out[r]['same'] == (float(world), 2), out[r]
+        assert out[r]['diverged'] == (True, True), out[r]
+        assert out[r]['untouched'] == 2048.0, out[r]                # the mismatched spans were never reduced
+        assert out[r]['unchecked'] == float(world)
